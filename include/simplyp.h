@@ -1,0 +1,186 @@
+/*
+ * simplyp.h -- C ABI of the MI355X SimplyP time-stepping engine (libsimplyp_hip.so).
+ *
+ * The reference (JoeyYHT/SimplyP, pure Python) has no FFI.  Its seam for this path is the
+ * double loop inside run_simply_p() -- `for SC in p['SC_list']` (model.py:365) x
+ * `for idx in range(len(met_df))` (model.py:491) around `odeint(ode_f, ...)` (model.py:640).
+ * Every entry point below replaces a piece of that loop nest; the Python host in
+ * simplyp_amd/ binds them with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; all pointers marked "device" are
+ *     device-resident (hipMalloc'd, e.g. torch CUDA tensors' data_ptr()), "host" are host.
+ *   - ensemble-major SoA: the member index e is always the fastest-varying one.
+ *   - every function returns 0 (SIMPLYP_OK) or a negative simplyp_status; no exceptions
+ *     cross the boundary; simplyp_last_error() gives the message for the last failure.
+ *   - the caller owns every buffer; the library keeps no pointer after a call returns.
+ */
+#ifndef SIMPLYP_H
+#define SIMPLYP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIMPLYP_ABI_VERSION 1
+
+typedef enum {
+    SIMPLYP_OK = 0,
+    SIMPLYP_ERR_ARG = -1,        /* bad dimension / option / NULL pointer            */
+    SIMPLYP_ERR_TOPOLOGY = -2,   /* upstream id >= own id, out of range, ...          */
+    SIMPLYP_ERR_DEVICE = -3,     /* HIP runtime error (message in simplyp_last_error) */
+    SIMPLYP_ERR_NOMEM = -4
+} simplyp_status;
+
+/* ---- per-member parameters: rows of member_params[SIMPLYP_NP_M][E] --------------------
+ * Raw reference parameters (sheet 'Constant' -> series p, sheet 'LU' -> frame p_LU); every
+ * derived quantity (mu model.py:349, initial conditions :377-459, Kf :449-453) is computed
+ * from these inside the kernel prologue, so an ensemble may perturb any of them.          */
+enum {
+    SIMPLYP_PM_F_QUICK = 0, SIMPLYP_PM_ALPHA, SIMPLYP_PM_FC, SIMPLYP_PM_BETA, SIMPLYP_PM_T_G,
+    SIMPLYP_PM_QG_MIN, SIMPLYP_PM_A_Q, SIMPLYP_PM_B_Q, SIMPLYP_PM_QR0_INIT, SIMPLYP_PM_MSOIL_M2,
+    SIMPLYP_PM_KF, SIMPLYP_PM_TDPG, SIMPLYP_PM_E_PP, SIMPLYP_PM_E_M, SIMPLYP_PM_K_M,
+    SIMPLYP_PM_D_MAXE_SPR, SIMPLYP_PM_D_MAXE_AUT,
+    SIMPLYP_PM_T_S_A, SIMPLYP_PM_T_S_S, SIMPLYP_PM_SOILPCONC_A, SIMPLYP_PM_SOILPCONC_S,
+    SIMPLYP_PM_P_NETINPUT_A, SIMPLYP_PM_P_NETINPUT_NC, SIMPLYP_PM_EPC0_INIT_A, SIMPLYP_PM_EPC0_INIT_S,
+    SIMPLYP_PM_C_COVER_A, SIMPLYP_PM_C_COVER_S, SIMPLYP_PM_C_COVER_IG,
+    SIMPLYP_PM_C_MEAS_A, SIMPLYP_PM_C_MEAS_S, SIMPLYP_PM_C_MEAS_IG,
+    SIMPLYP_NP_M
+};
+
+/* ---- per-reach parameters: rows of reach_params[SIMPLYP_NP_R][S][E] (sheet 'SC_reach') - */
+enum {
+    SIMPLYP_PR_A_CATCH = 0, SIMPLYP_PR_F_AR, SIMPLYP_PR_F_IG, SIMPLYP_PR_F_S,
+    SIMPLYP_PR_F_NC_AR, SIMPLYP_PR_F_NC_IG, SIMPLYP_PR_F_NC_S, SIMPLYP_PR_F_SPR,
+    SIMPLYP_PR_S_AR, SIMPLYP_PR_S_IG, SIMPLYP_PR_S_SN, SIMPLYP_PR_L_REACH, SIMPLYP_PR_S_REACH,
+    SIMPLYP_PR_TDPEFF,
+    SIMPLYP_NP_R
+};
+
+/* ---- output columns, in the reference's own order: 12 ODE results (model.py:737-739)
+ * followed by 13 non-ODE results (model.py:721-723, names :743-745).                     */
+enum {
+    SIMPLYP_OUT_VSA = 0, SIMPLYP_OUT_VSS, SIMPLYP_OUT_VG, SIMPLYP_OUT_VR, SIMPLYP_OUT_QR_END,
+    SIMPLYP_OUT_QR, SIMPLYP_OUT_MSUS_END, SIMPLYP_OUT_MSUS_FLUX, SIMPLYP_OUT_TDPR_END,
+    SIMPLYP_OUT_TDP_FLUX, SIMPLYP_OUT_PPR_END, SIMPLYP_OUT_PP_FLUX,
+    SIMPLYP_OUT_QQ, SIMPLYP_OUT_QSA, SIMPLYP_OUT_QSS, SIMPLYP_OUT_QG, SIMPLYP_OUT_C_COVER_A,
+    SIMPLYP_OUT_EPC0_A, SIMPLYP_OUT_EPC0_NC, SIMPLYP_OUT_TDPS_A, SIMPLYP_OUT_PLAB_A,
+    SIMPLYP_OUT_CONC_TDPS_A, SIMPLYP_OUT_TDPS_NC, SIMPLYP_OUT_PLAB_NC, SIMPLYP_OUT_CONC_TDPS_NC,
+    SIMPLYP_N_OUT
+};
+#define SIMPLYP_MASK_ALL    ((uint32_t)((1u << SIMPLYP_N_OUT) - 1u))
+/* the five documented model outputs of a reach (model.py:272-277): Vr, Qr, and the three
+ * daily fluxes */
+#define SIMPLYP_MASK_REACH5 ((1u << SIMPLYP_OUT_VR) | (1u << SIMPLYP_OUT_QR) | (1u << SIMPLYP_OUT_MSUS_FLUX) | \
+                             (1u << SIMPLYP_OUT_TDP_FLUX) | (1u << SIMPLYP_OUT_PP_FLUX))
+
+/* per-member status bits written to member_status[E] */
+#define SIMPLYP_STATUS_NONFINITE 1   /* a state became NaN/Inf                               */
+#define SIMPLYP_STATUS_STEPCAP   2   /* adaptive solver hit max_steps in some day            */
+
+typedef enum {
+    SIMPLYP_INTEG_RK4 = 0,       /* classical RK4, `substeps` equal steps per day            */
+    SIMPLYP_INTEG_CASHKARP = 1   /* Cash-Karp 5(4) embedded pair, per-thread step control    */
+} simplyp_integrator;
+
+typedef struct {
+    int32_t E;               /* ensemble members                                           */
+    int32_t S;               /* sub-catchments / reaches (ids 0..S-1 = reference SC 1..S)  */
+    int32_t D;               /* days                                                       */
+    int32_t n_forcing_sets;  /* >= 1                                                       */
+} simplyp_dims;
+
+typedef struct {
+    int32_t  integrator;     /* simplyp_integrator                                         */
+    int32_t  substeps;       /* RK4: steps per day.  Cash-Karp: first trial step = step_len/substeps */
+    double   rtol;           /* Cash-Karp: err_i <= atol + rtol*max(|y_i|,|ynew_i|)        */
+    double   atol;
+    int32_t  max_steps;      /* Cash-Karp: attempted steps per day before SIMPLYP_STATUS_STEPCAP */
+    int32_t  dynamic_epc0;   /* dynamic_options['Dynamic_EPC0'] == 'y'  (model.py:600,684) */
+    int32_t  dynamic_erod;   /* dynamic_options['Dynamic_erodibility'] == 'y' (model.py:555) */
+    int32_t  run_mode_cal;   /* p_SU.run_mode == 'cal' -> Kf calibrated (model.py:449-453) */
+    int32_t  sc_qr0;         /* zero-based reach that Qr0_init refers to (p['SC_Qr0']-1, model.py:386) */
+    uint32_t out_mask;       /* bit c set -> column c (SIMPLYP_OUT_*) is written           */
+    double   step_len;       /* integration span per day, model.py:345 (default 1.0)       */
+    int32_t  reserved0;
+    int32_t  reserved1;
+} simplyp_opts;
+
+typedef struct {
+    uint64_t rhs_evals;      /* right-hand-side evaluations, all members/reaches/days      */
+    uint64_t steps;          /* accepted steps                                             */
+    uint64_t rejected;       /* rejected steps (Cash-Karp)                                 */
+    double   kernel_ms;      /* device time of the launches of this run (HIP events)       */
+    int32_t  n_launches;     /* kernel launches issued (one per routing stage)             */
+    int32_t  reserved;
+} simplyp_stats;
+
+typedef struct simplyp_ctx simplyp_ctx;
+
+int  simplyp_abi_version(void);
+int  simplyp_device_count(void);
+
+/* A context is bound to one HIP device and owns a stream, two events and grow-only device
+ * scratch (routing series between reaches, launch schedule).  Not re-entrant; distinct
+ * contexts may be driven from distinct host threads. */
+int  simplyp_ctx_create(int device, simplyp_ctx** out);
+void simplyp_ctx_destroy(simplyp_ctx* ctx);
+const char* simplyp_last_error(const simplyp_ctx* ctx);   /* ctx may be NULL: create errors */
+
+/* Bytes of `out` that simplyp_run will write: popcount(out_mask) * D * n_out_reaches * E * 8. */
+int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, int32_t n_out_reaches);
+
+/*
+ * simplyp_run -- integrate every (member, reach) through all D days.
+ * Replaces model.py:365-724 for the whole ensemble in one call.
+ *
+ *   forcing           device  [n_forcing_sets][2][D]   row 0 = P (met_df['P'], model.py:497),
+ *                                                      row 1 = PET (model.py:498)
+ *   doy               device  [D]        day of year 1..366 (met_df.index[idx].dayofyear, :550)
+ *   forcing_of_member device  [E] or NULL (all members use set 0)
+ *   member_params     device  [SIMPLYP_NP_M][E]
+ *   reach_params      device  [SIMPLYP_NP_R][S][E]
+ *   up_ptr, up_idx    host    CSR of directly-upstream reaches (p_struc 'Upstream_SCs',
+ *                             model.py:480-487), zero-based, up_idx[k] < own id, shared by all
+ *                             members; up_ptr has S+1 entries
+ *   out_reaches       host    [n_out_reaches] reaches whose columns are written, or NULL = all S
+ *   out               device  [n_cols][D][n_out_reaches][E] fp64, n_cols = popcount(out_mask),
+ *                             columns in ascending SIMPLYP_OUT_* order
+ *   member_status     device  [E] int32, OR of SIMPLYP_STATUS_* bits (zeroed by the call)
+ *   stats             host    may be NULL
+ *
+ * The call is synchronous: it returns after the last kernel has finished.
+ */
+int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
+                const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                const double* member_params, const double* reach_params,
+                const int32_t* up_ptr, const int32_t* up_idx,
+                const int32_t* out_reaches, int32_t n_out_reaches,
+                double* out, int32_t* member_status, simplyp_stats* stats);
+
+/* Same as simplyp_run but only enqueues on the context's stream (for overlap with the
+ * caller's own copies); simplyp_sync() waits and fills `stats`. */
+int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
+                      const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                      const double* member_params, const double* reach_params,
+                      const int32_t* up_ptr, const int32_t* up_idx,
+                      const int32_t* out_reaches, int32_t n_out_reaches,
+                      double* out, int32_t* member_status);
+int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats);
+
+/* Host-pinned staging buffers for callers that do not use torch (hipHostMalloc/hipHostFree). */
+void* simplyp_host_alloc(int64_t bytes);
+void  simplyp_host_free(void* p);
+
+/* Plain device buffers + copies for callers without a device allocator of their own. */
+void* simplyp_device_alloc(simplyp_ctx* ctx, int64_t bytes);
+void  simplyp_device_free(simplyp_ctx* ctx, void* p);
+int   simplyp_memcpy_h2d(simplyp_ctx* ctx, void* dst, const void* src, int64_t bytes);
+int   simplyp_memcpy_d2h(simplyp_ctx* ctx, void* dst, const void* src, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMPLYP_H */

@@ -1,0 +1,506 @@
+/*
+ * simplyp_oracle.c -- TEST INFRASTRUCTURE ONLY.  Not part of the product.
+ *
+ * A scalar fp64 CPU restatement of the reference's time-stepping path
+ * (/root/reference/Current_Release/v0-2A/simplyP/model.py), written formula by formula in
+ * the reference's own order, so that the HIP kernel can be checked against it on a machine
+ * where the Python reference does not exist.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this; the product path never does.
+ *
+ * Pinning (tests/test_oracle_*.py, fixtures in tests/golden/ made by make_golden.py from the
+ * unmodified reference):
+ *   - oracle_fx / oracle_soilp / oracle_ode_f  ==  reference f_x / discretized_soilP / ode_f
+ *     on the committed in/out vectors (1e-13 rel);
+ *   - the full driver with a converged integrator == reference run_simply_p with
+ *     odeint(rtol=atol=1e-12) on 4 scenarios (tolerance stated in the tests).
+ * The integrator itself is NOT the reference's: the reference calls SciPy odeint = ODEPACK
+ * LSODA (scipy is un-vendored; reference pins scipy 1.2.0 in README.md:39, 1.15.3 here) at
+ * rtol=0.01 (model.py:640).  LSODA's step/order heuristics are not restated; the oracle
+ * integrates the same right-hand side with classical RK4 or Cash-Karp 5(4), the two schemes
+ * the device kernel implements.  For the LSODA-at-rtol=0.01 trajectory itself: parity
+ * unpinned (the reference's own shipped CSVs pin it only to ~3e-3).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/simplyp.h"
+
+/* ------------------------------------------------------------------------------------- */
+/* f_x, model.py:23-37.  threshold == 0 gives d == 0: the reference then divides 0/0 on the
+ * single point x == 0; defined here (and in the kernel) as a plain step.                  */
+static double f_x(double x, double threshold, double reld)
+{
+    double d = threshold * reld;
+    if (x < threshold) return 0.0;
+    if (x > threshold + d) return 1.0;
+    if (d == 0.0) return 0.0;            /* x == threshold == 0 */
+    double s = (x - threshold) / d;
+    return -2.0 * s * s * s + 3.0 * s * s;                      /* :33 */
+}
+
+/* discretized_soilP, model.py:39-56 */
+static void discretized_soilP(double P_netInput, double A_catch, double Kf, double Msoil, double EPC0,
+                              double Qs, double Qq, double Vs, double TDPs, double Plab,
+                              double* TDPs_out, double* Plab_out)
+{
+    double a = P_netInput * A_catch * 100.0 / 365. + Kf * Msoil * EPC0;          /* :42 */
+    double b = (Kf * Msoil + Qs + Qq) / Vs;                                      /* :43 */
+    TDPs = a / b + (TDPs - a / b) * exp(-b);                                     /* :44 */
+    double b0 = b * Vs;                                                          /* :47 */
+    double sorp;
+    if (Vs > 0)                                                                  /* :50 */
+        sorp = Kf * Msoil * (a / b0 - EPC0 + (1 / b) * (TDPs / Vs - a / b0) * (1 - exp(-b)));   /* :51 */
+    else
+        sorp = 0.;
+    *TDPs_out = TDPs;
+    *Plab_out = Plab + sorp;                                                     /* :54 */
+}
+
+/* Everything ode_f unpacks from its 41-tuple (model.py:74-78) that it actually uses. */
+typedef struct {
+    double P, E, mu, Qq_i, Qr_US_i, Esus_A, Esus_S, Esus_IG, Msus_US_i, TDPr_US_i, PPr_US_i;
+    double f_A, f_Ar, f_IG, f_S, f_NC_A, f_NC_Ar, f_NC_IG, f_NC_S;
+    int    NC_type;          /* 0 'None', 1 'A', 2 'S' */
+    double f_quick, alpha, beta, T_s_A, T_s_S, T_g, fc, L_reach, A_catch, a_Q, b_Q, k_M;
+    double conc_TDPs_A, conc_TDPs_NC, PlabA_i, PlabNC_i, Msoil, TDPeff, TDPg, E_PP, P_inactive, Qg_min;
+} ode_params;
+
+/* ode_f, model.py:58-187.  y and dy have the reference's 12 slots. */
+static void ode_f(const double* y, const ode_params* p, double* dy)
+{
+    double VsA_i = y[0], VsS_i = y[1], Vg_i = y[2], Vr_i = y[3], Qr_i = y[4];
+    double Msus_i = y[6], TDPr_i = y[8], PPr_i = y[10];
+
+    double QsA_i = (VsA_i - p->fc) * f_x(VsA_i, p->fc, 0.01) / p->T_s_A;                         /* :105 */
+    double dVsA_dt = p->P * (1 - p->f_quick) - p->alpha * p->E * (1 - exp(-p->mu * VsA_i)) - QsA_i;  /* :106 */
+    double QsS_i = (VsS_i - p->fc) * f_x(VsS_i, p->fc, 0.01) / p->T_s_S;                         /* :109 */
+    double dVsS_dt = p->P * (1 - p->f_quick) - p->alpha * p->E * (1 - exp(-p->mu * VsS_i)) - QsS_i;  /* :110 */
+
+    double QsNC_i = (p->NC_type == 1) ? QsA_i : QsS_i;                                           /* :113-118 */
+
+    double f_Qg = f_x(Vg_i / p->T_g, p->Qg_min, 0.01);                                           /* :121 */
+    double Qg_i = (1 - f_Qg) * p->Qg_min + f_Qg * (Vg_i / p->T_g);                               /* :122 */
+    double dVg_dt = p->beta * (p->f_A * QsA_i + p->f_S * QsS_i) - Qg_i;                          /* :124 */
+
+    double inflow = p->Qq_i + (1 - p->beta) * (p->f_A * QsA_i + p->f_S * QsS_i) + Qg_i + p->Qr_US_i - Qr_i;
+    double dQr_dt = inflow * p->a_Q * pow(Qr_i, p->b_Q) * (8.64 * 10000) / ((1 - p->b_Q) * (p->L_reach));  /* :127-130 */
+    double dVr_dt = inflow;                                                                      /* :131 */
+    double dQr_av_dt = Qr_i;                                                                     /* :132 */
+
+    double QrkM = pow(Qr_i, p->k_M);
+    double Msus_in_A = p->Esus_A * QrkM, Msus_in_S = p->Esus_S * QrkM, Msus_in_IG = p->Esus_IG * QrkM;  /* :138 */
+    double dMsus_dt = p->f_Ar * Msus_in_A + p->f_IG * Msus_in_IG + p->f_S * Msus_in_S
+                      + p->Msus_US_i - (Msus_i / Vr_i) * Qr_i;                                   /* :141-145 */
+    double dMsus_out_dt = (Msus_i / Vr_i) * Qr_i;                                                /* :147 */
+
+    double dTDPr_dt = ((1 - p->beta) *
+                       (p->f_A * (1 - p->f_NC_A) * QsA_i * (p->conc_TDPs_A)
+                        + p->f_A * p->f_NC_A * QsNC_i * (p->conc_TDPs_NC)
+                        + p->f_S * p->f_NC_S * QsNC_i * (p->conc_TDPs_NC))
+                       + p->f_A * (1 - p->f_NC_A) * p->Qq_i * (p->conc_TDPs_A)
+                       + p->f_A * p->f_NC_A * p->Qq_i * (p->conc_TDPs_NC)
+                       + p->f_S * p->f_NC_S * p->Qq_i * (p->conc_TDPs_NC)
+                       + Qg_i * (p->TDPg * p->A_catch)
+                       + p->TDPeff
+                       + p->TDPr_US_i
+                       - Qr_i * (TDPr_i / Vr_i));                                                /* :154-166 */
+    double dTDPr_out_dt = Qr_i * (TDPr_i / Vr_i);                                                /* :168 */
+
+    double dPPr_dt = (p->E_PP * (p->f_Ar * (1 - p->f_NC_Ar) * Msus_in_A * (p->PlabA_i + p->P_inactive) / p->Msoil
+                                 + p->f_IG * (1 - p->f_NC_IG) * Msus_in_IG * (p->PlabA_i + p->P_inactive) / p->Msoil
+                                 + p->f_S * (1 - p->f_NC_S) * Msus_in_S * p->P_inactive / p->Msoil
+                                 + p->f_Ar * p->f_NC_Ar * Msus_in_A * (p->PlabNC_i + p->P_inactive) / p->Msoil
+                                 + p->f_IG * p->f_NC_IG * Msus_in_IG * (p->PlabNC_i + p->P_inactive) / p->Msoil
+                                 + p->f_S * p->f_NC_S * Msus_in_S * (p->PlabNC_i + p->P_inactive) / p->Msoil)
+                      + p->PPr_US_i
+                      - Qr_i * (PPr_i / Vr_i));                                                  /* :171-178 */
+    double dPPr_out_dt = Qr_i * PPr_i / Vr_i;                                                    /* :180 */
+
+    dy[0] = dVsA_dt; dy[1] = dVsS_dt; dy[2] = dVg_dt; dy[3] = dVr_dt; dy[4] = dQr_dt; dy[5] = dQr_av_dt;
+    dy[6] = dMsus_dt; dy[7] = dMsus_out_dt; dy[8] = dTDPr_dt; dy[9] = dTDPr_out_dt; dy[10] = dPPr_dt;
+    dy[11] = dPPr_out_dt;                                                                        /* :184-185 */
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* Integrators over [0, T] for the autonomous 12-system.                                  */
+
+#define NY 12
+
+typedef struct { uint64_t rhs, steps, rejected; int capped; } integ_stats;
+
+static void rk4_day(double* y, const ode_params* p, double T, int n, integ_stats* st)
+{
+    double h = T / n, k1[NY], k2[NY], k3[NY], k4[NY], yt[NY];
+    for (int s = 0; s < n; ++s) {
+        ode_f(y, p, k1);
+        for (int i = 0; i < NY; ++i) yt[i] = y[i] + 0.5 * h * k1[i];
+        ode_f(yt, p, k2);
+        for (int i = 0; i < NY; ++i) yt[i] = y[i] + 0.5 * h * k2[i];
+        ode_f(yt, p, k3);
+        for (int i = 0; i < NY; ++i) yt[i] = y[i] + h * k3[i];
+        ode_f(yt, p, k4);
+        for (int i = 0; i < NY; ++i) y[i] += h * (1.0 / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+    st->rhs += 4u * (uint64_t)n; st->steps += (uint64_t)n;
+}
+
+/* Embedded explicit RK pair described by a Butcher tableau (up to 7 stages). */
+typedef struct {
+    int stages, fsal, order;        /* order = order of the propagated solution */
+    double c[7], a[7][6], b[7], e[7];   /* e = b - bhat (error weights) */
+} tableau;
+
+static const tableau CASH_KARP = {
+    6, 0, 5,
+    {0, 1.0 / 5, 3.0 / 10, 3.0 / 5, 1.0, 7.0 / 8, 0},
+    {{0},
+     {1.0 / 5},
+     {3.0 / 40, 9.0 / 40},
+     {3.0 / 10, -9.0 / 10, 6.0 / 5},
+     {-11.0 / 54, 5.0 / 2, -70.0 / 27, 35.0 / 27},
+     {1631.0 / 55296, 175.0 / 512, 575.0 / 13824, 44275.0 / 110592, 253.0 / 4096},
+     {0}},
+    {37.0 / 378, 0, 250.0 / 621, 125.0 / 594, 0, 512.0 / 1771, 0},
+    {37.0 / 378 - 2825.0 / 27648, 0, 250.0 / 621 - 18575.0 / 48384, 125.0 / 594 - 13525.0 / 55296,
+     -277.0 / 14336, 512.0 / 1771 - 1.0 / 4, 0}
+};
+
+/* Dormand-Prince 5(4) -- experimental comparison scheme (integrator id 2), not in the ABI. */
+static const tableau DOPRI5 = {
+    7, 1, 5,
+    {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0},
+    {{0},
+     {1.0 / 5},
+     {3.0 / 40, 9.0 / 40},
+     {44.0 / 45, -56.0 / 15, 32.0 / 9},
+     {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
+     {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
+     {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0},
+    {35.0 / 384 - 5179.0 / 57600, 0, 500.0 / 1113 - 7571.0 / 16695, 125.0 / 192 - 393.0 / 640,
+     -2187.0 / 6784 + 92097.0 / 339200, 11.0 / 84 - 187.0 / 2100, -1.0 / 40}
+};
+
+/*
+ * Adaptive step control -- the exact rule the device kernel mirrors:
+ *   trial step hh = h, except  rem <= 1.1 h -> hh = rem;  rem < 2 h -> hh = rem/2   (rem = T - t)
+ *   err = max_i |e_i| / (atol + rtol * max(|y_i|, |ynew_i|))
+ *   accept iff err <= 1 (or the step cap was hit, or hh <= 1e-9 T: forced)
+ *   h <- hh * clamp(0.9 * err^(-1/5), 0.2, 5)      (err == 0 -> 5; non-finite err -> 0.2)
+ *   *h_carry (the controller's h) persists from day to day.
+ */
+static void embedded_day(const tableau* tb, double* y, const ode_params* p, double T, double rtol, double atol,
+                         int max_steps, double* h_carry, integ_stats* st)
+{
+    double k[7][NY], yt[NY], yn[NY];
+    double t = 0.0, h = *h_carry;
+    int attempts = 0, have_k1 = 0;
+    if (!(h > 0.0) || h > T) h = T;
+    while (t < T) {
+        double rem = T - t, hh = h;
+        if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
+        if (!have_k1) { ode_f(y, p, k[0]); st->rhs++; }
+        for (int s = 1; s < tb->stages; ++s) {
+            for (int i = 0; i < NY; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < s; ++j) acc += tb->a[s][j] * k[j][i];
+                yt[i] = y[i] + hh * acc;
+            }
+            ode_f(yt, p, k[s]); st->rhs++;
+        }
+        double err = 0.0; int bad = 0;
+        for (int i = 0; i < NY; ++i) {
+            double inc = 0.0, ee = 0.0;
+            for (int s = 0; s < tb->stages; ++s) { inc += tb->b[s] * k[s][i]; ee += tb->e[s] * k[s][i]; }
+            yn[i] = y[i] + hh * inc;
+            double sc = atol + rtol * fmax(fabs(y[i]), fabs(yn[i]));
+            double r = fabs(hh * ee) / sc;
+            if (!isfinite(r)) bad = 1; else if (r > err) err = r;
+        }
+        ++attempts;
+        int forced = (attempts >= max_steps) || (hh <= 1e-9 * T);
+        if (attempts >= max_steps) st->capped = 1;
+        double fac;
+        if (bad) fac = 0.2;
+        else if (err == 0.0) fac = 5.0;
+        else { fac = 0.9 * pow(err, -0.2); if (fac < 0.2) fac = 0.2; if (fac > 5.0) fac = 5.0; }
+        if ((!bad && err <= 1.0) || forced) {
+            memcpy(y, yn, sizeof(yn));
+            t += hh; if (hh == rem) t = T;
+            st->steps++;
+            if (tb->fsal) { memcpy(k[0], k[tb->stages - 1], sizeof(k[0])); have_k1 = 1; }
+            else have_k1 = 0;
+        } else {
+            st->rejected++;
+            have_k1 = 1;
+        }
+        h = hh * fac;
+    }
+    *h_carry = h;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* One member: the SC loop (model.py:365) around the day loop (model.py:491).              */
+
+#define MP(name) (mp[(size_t)SIMPLYP_PM_##name * E + e])
+#define RP(name, s) (rp[((size_t)SIMPLYP_PR_##name * S + (s)) * E + e])
+
+static int nc_type_of(double f_NC_A, double f_NC_S)     /* model.py:325-334 */
+{
+    if (f_NC_A > 0) return 1;
+    else if (f_NC_S > 0) return 2;
+    return 0;
+}
+
+static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, const double* forcing,
+                       const int32_t* doy, const int32_t* fom, const double* mp, const double* rp,
+                       const int32_t* up_ptr, const int32_t* up_idx, const int32_t* out_slot,
+                       int n_out_reaches, int n_integ, double* out, int32_t* status, integ_stats* st)
+{
+    const int E = dims->E, S = dims->S, D = dims->D;
+    const double* Pser = forcing + (size_t)(fom ? fom[e] : 0) * 2 * D;
+    const double* Eser = Pser + D;
+    /* daily series of every reach of this member that a downstream reach may read (:524-528) */
+    double* route = (double*)malloc(sizeof(double) * 4 * (size_t)S * D);
+    int col_of[SIMPLYP_N_OUT], ncols = 0;
+    for (int c = 0; c < SIMPLYP_N_OUT; ++c) col_of[c] = (o->out_mask >> c) & 1u ? ncols++ : -1;
+    int32_t stat = 0;
+
+    const double fc = MP(FC), f_quick = MP(F_QUICK), alpha = MP(ALPHA), beta = MP(BETA), T_g = MP(T_G);
+    const double Qg_min = MP(QG_MIN), a_Q = MP(A_Q), b_Q = MP(B_Q), E_M = MP(E_M), k_M = MP(K_M);
+    const double T_s_A = MP(T_S_A), T_s_S = MP(T_S_S);
+    const double mu = -log(0.01) / fc;                                                           /* :349 */
+    const double E_risk_period = 60.0;                                                           /* :354 */
+    const double d_mid[2] = {MP(D_MAXE_SPR), MP(D_MAXE_AUT)};
+    const double d_start[2] = {d_mid[0] - E_risk_period / 2., d_mid[1] - E_risk_period / 2.};    /* :358 */
+    const double d_end[2] = {d_mid[0] + E_risk_period / 2., d_mid[1] + E_risk_period / 2.};      /* :359 */
+
+    /* the Python variable NC_type left over from the validation loop (:321-335) = last SC's */
+    const int NC_type_leak = nc_type_of(RP(F_AR, S - 1) * RP(F_NC_AR, S - 1) + RP(F_NC_IG, S - 1) * RP(F_IG, S - 1),
+                                        RP(F_NC_S, S - 1));
+
+    for (int s = 0; s < S; ++s) {                                                                /* :365 */
+        const double A_catch = RP(A_CATCH, s);
+        const double f_Ar = RP(F_AR, s), f_IG = RP(F_IG, s), f_S = RP(F_S, s);
+        const double f_NC_Ar = RP(F_NC_AR, s), f_NC_IG = RP(F_NC_IG, s), f_NC_S = RP(F_NC_S, s);
+        const double f_A = f_IG + f_Ar;                                                          /* :318 */
+        const double f_NC_A = (f_Ar * f_NC_Ar) + (f_NC_IG * f_IG);                               /* :319 */
+        const int NC_type = nc_type_of(f_NC_A, f_NC_S);
+
+        double VsA0 = fc, VsS0 = VsA0;                                                           /* :377-378 */
+        double Qr0 = MP(QR0_INIT) * 86400 / (1000 * RP(A_CATCH, o->sc_qr0));                     /* :386, hf.py:29 */
+        double Qg0 = beta * Qr0;                                                                 /* :389 */
+        double Vg0 = Qg0 * T_g;                                                                  /* :390 */
+        double TDPr0 = 0.0, PPr0 = 0.0, Msus0 = 0.0;                                             /* :396 */
+        const double Msoil = MP(MSOIL_M2) * 1000000 * A_catch;                                   /* :404 */
+        const double P_inactive = 1e-6 * MP(SOILPCONC_S) * Msoil;                                /* :407 */
+        const double EPC0_0_A = MP(EPC0_INIT_A) * A_catch;                                       /* :412, hf.py:56 */
+        const double EPC0_0_S = MP(EPC0_INIT_S) * A_catch;
+        const double Plab0_A_init = 1e-6 * (MP(SOILPCONC_A) - MP(SOILPCONC_S)) * Msoil;          /* :415 */
+        const double TDPs0_A_init = EPC0_0_A * VsA0;                                             /* :420 */
+        const double TDPs0_S_init = 0;                                                           /* :422 */
+        double Plab0_A = Plab0_A_init, TDPs0_A = TDPs0_A_init;                                   /* :426 */
+        double Plab0_NC, TDPs0_NC;
+        if (NC_type == 2) { Plab0_NC = Plab0_A; TDPs0_NC = TDPs0_A; }                            /* :429-431 */
+        else { Plab0_NC = 0.0; TDPs0_NC = TDPs0_S_init; }                                        /* :433-434 */
+        double conc_TDPs_A = TDPs0_A / VsA0;                                                     /* :438 */
+        double VsNC0 = (NC_type_leak == 1) ? VsA0 : VsS0;                                        /* :442-445 */
+        double conc_TDPs_NC = TDPs0_NC / VsNC0;                                                  /* :446 */
+        double Kf;
+        if (o->run_mode_cal) Kf = 1e-6 * (MP(SOILPCONC_A) - MP(SOILPCONC_S)) / EPC0_0_A;         /* :451 */
+        else Kf = MP(KF);                                                                        /* :453 */
+        const double L_reach = RP(L_REACH, s);
+        double Tr0 = L_reach / (a_Q * pow(Qr0, b_Q) * 8.64 * 10000);                             /* :457-458 */
+        double Vr0 = Tr0 * Qr0;                                                                  /* :459 */
+        double TDPeff = RP(TDPEFF, s);
+        if (isnan(TDPeff)) TDPeff = 0.;                                                          /* :462-463 */
+        const double slope_A = RP(S_AR, s), slope_IG = RP(S_IG, s), slope_S = RP(S_SN, s);       /* :469 */
+        const double S_reach = RP(S_REACH, s), f_spr = RP(F_SPR, s);
+
+        double h_carry = o->step_len / (o->substeps > 0 ? o->substeps : 1);
+
+        for (int idx = 0; idx < D; ++idx) {                                                      /* :491 */
+            double P = Pser[idx], Ev = Eser[idx];                                                /* :497-498 */
+            double Qq_i = f_quick * P;                                                           /* :501 */
+
+            double Qr_US_i = 0.0, Msus_US_i = 0.0, TDPr_US_i = 0.0, PPr_US_i = 0.0;              /* :544 */
+            for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) {                                    /* :521-538 */
+                int u = up_idx[k];
+                const double* r = route + ((size_t)u * D + idx) * 4;
+                Qr_US_i += r[0] * (RP(A_CATCH, u) / A_catch);                                    /* :524-525 */
+                Msus_US_i += r[1]; TDPr_US_i += r[2]; PPr_US_i += r[3];                          /* :526-528 */
+            }
+
+            /* sediment input coefficients, :549-594 */
+            double C_cover_A;
+            if (o->dynamic_erod) {
+                int dayNo = doy[idx];                                                            /* :550 */
+                double C_season[2];
+                for (int q = 0; q < 2; ++q) {
+                    /* `dayNo in np.arange(d_start, d_end)` (:567): exact float membership */
+                    double kk = (double)dayNo - d_start[q];
+                    int in_window = (kk >= 0.0 && kk == floor(kk) && kk < ceil(d_end[q] - d_start[q])
+                                     && d_start[q] + kk == (double)dayNo);
+                    if (in_window) {
+                        if (dayNo < d_mid[q])                                                    /* :568-570, hf.py:90 */
+                            C_season[q] = MP(C_COVER_A) + (1.0 - MP(C_COVER_A)) * (dayNo - d_start[q]) / (d_mid[q] - d_start[q]);
+                        else                                                                     /* :572-573 */
+                            C_season[q] = 1.0 + (MP(C_COVER_A) - 1.0) * (dayNo - d_mid[q]) / (d_end[q] - d_mid[q]);
+                    } else {
+                        C_season[q] = (MP(C_COVER_A) - (E_risk_period * (1 - MP(C_COVER_A))
+                                                       / (2 * (365 - E_risk_period))));          /* :575-576 */
+                    }
+                }
+                C_cover_A = (f_spr * C_season[0] + (1 - f_spr) * C_season[1]);                   /* :579-580 */
+            } else {
+                C_cover_A = MP(C_COVER_A);                                                       /* :583 */
+            }
+            double Esus_A = (E_M * S_reach * slope_A * C_cover_A * (1 - MP(C_MEAS_A)));          /* :591-594 */
+            double Esus_S = (E_M * S_reach * slope_S * MP(C_COVER_S) * (1 - MP(C_MEAS_S)));
+            double Esus_IG = (E_M * S_reach * slope_IG * MP(C_COVER_IG) * (1 - MP(C_MEAS_IG)));
+
+            double EPC0_A_i, EPC0_NC_i;
+            if (o->dynamic_epc0) {
+                EPC0_A_i = fmax(Plab0_A / (Kf * Msoil), 0);                                      /* :602 */
+                EPC0_NC_i = fmax(Plab0_NC / (Kf * Msoil), 0);                                    /* :603 */
+            } else {
+                EPC0_A_i = EPC0_0_A;                                                             /* :607 */
+                EPC0_NC_i = (NC_type == 2) ? EPC0_0_A : EPC0_0_S;                                /* :608-611 */
+            }
+
+            double y[NY] = {VsA0, VsS0, Vg0, Vr0, Qr0, 0.0, Msus0, 0.0, TDPr0, 0.0, PPr0, 0.0};  /* :618 */
+            ode_params op;                                                                       /* :622-632 */
+            op.P = P; op.E = Ev; op.mu = mu; op.Qq_i = Qq_i; op.Qr_US_i = Qr_US_i;
+            op.Esus_A = Esus_A; op.Esus_S = Esus_S; op.Esus_IG = Esus_IG;
+            op.Msus_US_i = Msus_US_i; op.TDPr_US_i = TDPr_US_i; op.PPr_US_i = PPr_US_i;
+            op.f_A = f_A; op.f_Ar = f_Ar; op.f_IG = f_IG; op.f_S = f_S; op.f_NC_A = f_NC_A;
+            op.f_NC_Ar = f_NC_Ar; op.f_NC_IG = f_NC_IG; op.f_NC_S = f_NC_S; op.NC_type = NC_type;
+            op.f_quick = f_quick; op.alpha = alpha; op.beta = beta; op.T_s_A = T_s_A; op.T_s_S = T_s_S;
+            op.T_g = T_g; op.fc = fc; op.L_reach = L_reach; op.A_catch = A_catch; op.a_Q = a_Q; op.b_Q = b_Q;
+            op.k_M = k_M; op.conc_TDPs_A = conc_TDPs_A; op.conc_TDPs_NC = conc_TDPs_NC;
+            op.PlabA_i = Plab0_A; op.PlabNC_i = Plab0_NC; op.Msoil = Msoil; op.TDPeff = TDPeff;
+            op.TDPg = MP(TDPG); op.E_PP = MP(E_PP); op.P_inactive = P_inactive; op.Qg_min = Qg_min;
+
+            /* model.py:640 -- the one place that is not a restatement (see header) */
+            if (n_integ == SIMPLYP_INTEG_RK4) rk4_day(y, &op, o->step_len, o->substeps, st);
+            else embedded_day(n_integ == 2 ? &DOPRI5 : &CASH_KARP, y, &op, o->step_len, o->rtol, o->atol,
+                              o->max_steps, &h_carry, st);
+            const double* res = y;                                                               /* :643 */
+            for (int i = 0; i < NY; ++i) if (!isfinite(res[i])) stat |= SIMPLYP_STATUS_NONFINITE;
+
+            VsA0 = res[0]; VsS0 = res[1]; Vg0 = res[2]; Vr0 = res[3]; Qr0 = res[4];              /* :648-652 */
+            Msus0 = res[6]; TDPr0 = res[8]; PPr0 = res[10];                                      /* :654-658 */
+
+            double QsA0 = (VsA0 - fc) * f_x(VsA0, fc, 0.01) / T_s_A;                             /* :663 */
+            double QsS0 = (VsS0 - fc) * f_x(VsS0, fc, 0.01) / T_s_S;                             /* :664 */
+            double f_Qg = f_x(Vg0 / T_g, Qg_min, 0.01);                                          /* :668 */
+            Qg0 = (1 - f_Qg) * Qg_min + f_Qg * (Vg0 / T_g);                                      /* :669 */
+            Vg0 = Qg0 * T_g;                                                                     /* :670 */
+
+            double QsNC0;
+            if (NC_type_leak == 1) { VsNC0 = VsA0; QsNC0 = QsA0; }                               /* :676-678 */
+            else { VsNC0 = VsS0; QsNC0 = QsS0; }                                                 /* :680-681 */
+
+            if (o->dynamic_epc0) {                                                               /* :684 */
+                discretized_soilP(MP(P_NETINPUT_A), A_catch, Kf, Msoil, EPC0_A_i, QsA0, Qq_i, VsA0,
+                                  TDPs0_A, Plab0_A, &TDPs0_A, &Plab0_A);                         /* :688-689 */
+                discretized_soilP(MP(P_NETINPUT_NC), A_catch, Kf, Msoil, EPC0_NC_i, QsNC0, Qq_i, VsNC0,
+                                  TDPs0_NC, Plab0_NC, &TDPs0_NC, &Plab0_NC);                     /* :692-693 */
+                /* Python max(a, 0.) returns a when a is NaN; fmax would return 0 */
+                TDPs0_A = (0. > TDPs0_A) ? 0. : TDPs0_A;                                         /* :696 */
+                Plab0_A = (0. > Plab0_A) ? 0. : Plab0_A;                                         /* :697 */
+                TDPs0_NC = (0. > TDPs0_NC) ? 0. : TDPs0_NC;                                      /* :698 */
+                Plab0_NC = (0. > Plab0_NC) ? 0. : Plab0_NC;                                      /* :699 */
+                conc_TDPs_A = TDPs0_A / VsA0;                                                    /* :702 */
+                conc_TDPs_NC = TDPs0_NC / VsNC0;                                                 /* :703 */
+            } else {
+                conc_TDPs_A = EPC0_A_i;                                                          /* :711 */
+                conc_TDPs_NC = EPC0_NC_i;                                                        /* :715 */
+            }
+
+            double* r = route + ((size_t)s * D + idx) * 4;
+            r[0] = res[5]; r[1] = res[7]; r[2] = res[9]; r[3] = res[11];
+
+            int slot = out_slot[s];
+            if (slot >= 0) {
+                double row[SIMPLYP_N_OUT];
+                for (int i = 0; i < NY; ++i) row[i] = res[i];                                    /* :644 */
+                row[12] = Qq_i; row[13] = QsA0; row[14] = QsS0; row[15] = Qg0; row[16] = C_cover_A;   /* :721 */
+                row[17] = EPC0_A_i; row[18] = EPC0_NC_i; row[19] = TDPs0_A; row[20] = Plab0_A;
+                row[21] = conc_TDPs_A; row[22] = TDPs0_NC; row[23] = Plab0_NC; row[24] = conc_TDPs_NC; /* :722-723 */
+                for (int c = 0; c < SIMPLYP_N_OUT; ++c)
+                    if (col_of[c] >= 0)
+                        out[(((size_t)col_of[c] * D + idx) * n_out_reaches + slot) * E + e] = row[c];
+            }
+        }
+    }
+    if (st->capped) stat |= SIMPLYP_STATUS_STEPCAP;
+    status[e] = stat;
+    free(route);
+}
+
+/* Same arguments as simplyp_run() minus the context; every pointer is a host pointer.
+ * opts->integrator: 0 RK4, 1 Cash-Karp, 2 Dormand-Prince (oracle-only experiment). */
+int simplyp_oracle_run(const simplyp_dims* dims, const simplyp_opts* opts,
+                       const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                       const double* member_params, const double* reach_params,
+                       const int32_t* up_ptr, const int32_t* up_idx,
+                       const int32_t* out_reaches, int32_t n_out_reaches,
+                       double* out, int32_t* member_status, simplyp_stats* stats, int n_threads)
+{
+    if (!dims || !opts || dims->E <= 0 || dims->S <= 0 || dims->D <= 0) return SIMPLYP_ERR_ARG;
+    const int S = dims->S;
+    int32_t* out_slot = (int32_t*)malloc(sizeof(int32_t) * S);
+    for (int s = 0; s < S; ++s) out_slot[s] = out_reaches ? -1 : s;
+    if (out_reaches) for (int k = 0; k < n_out_reaches; ++k) out_slot[out_reaches[k]] = k;
+    else n_out_reaches = S;
+    for (int s = 0; s < S; ++s)
+        for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k)
+            if (up_idx[k] < 0 || up_idx[k] >= s) { free(out_slot); return SIMPLYP_ERR_TOPOLOGY; }
+    uint64_t rhs = 0, steps = 0, rej = 0;
+    (void)n_threads;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rhs, steps, rej)
+#endif
+    for (int e = 0; e < dims->E; ++e) {
+        integ_stats st = {0, 0, 0, 0};
+        run_member(e, dims, opts, forcing, doy, forcing_of_member, member_params, reach_params, up_ptr, up_idx,
+                   out_slot, n_out_reaches, opts->integrator, out, member_status, &st);
+        rhs += st.rhs; steps += st.steps; rej += st.rejected;
+    }
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->rhs_evals = rhs; stats->steps = steps; stats->rejected = rej; }
+    free(out_slot);
+    return SIMPLYP_OK;
+}
+
+/* ---- scalar entry points used to pin the restatement against tests/golden/unit_vectors.npz */
+double simplyp_oracle_fx(double x, double threshold, double reld) { return f_x(x, threshold, reld); }
+
+void simplyp_oracle_soilp(const double* in10, double* out2)
+{   /* in10 = P_netInput, A_catch, Kf, Msoil, EPC0, Qs, Qq, Vs, TDPs, Plab */
+    discretized_soilP(in10[0], in10[1], in10[2], in10[3], in10[4], in10[5], in10[6], in10[7], in10[8], in10[9],
+                      &out2[0], &out2[1]);
+}
+
+void simplyp_oracle_ode_f(const double* y12, const double* p43, double* dy12)
+{   /* p43 in the order of unit_vectors.npz 'ode_p_names' */
+    ode_params p;
+    p.P = p43[0]; p.E = p43[1]; p.mu = p43[2]; p.Qq_i = p43[3]; p.Qr_US_i = p43[4];
+    p.Esus_A = p43[5]; p.Esus_S = p43[6]; p.Esus_IG = p43[7];
+    p.Msus_US_i = p43[8]; p.TDPr_US_i = p43[9]; p.PPr_US_i = p43[10];
+    p.f_A = p43[11]; p.f_Ar = p43[12]; p.f_IG = p43[13]; p.f_S = p43[14]; p.f_NC_A = p43[15];
+    p.f_NC_Ar = p43[16]; p.f_NC_IG = p43[17]; p.f_NC_S = p43[18]; p.NC_type = (int)p43[19];
+    p.f_quick = p43[20]; p.alpha = p43[21]; p.beta = p43[22]; p.T_s_A = p43[23]; p.T_s_S = p43[24];
+    p.T_g = p43[25]; p.fc = p43[26]; p.L_reach = p43[27]; p.A_catch = p43[28]; p.a_Q = p43[29];
+    p.b_Q = p43[30]; /* p43[31] = E_M, unused inside ode_f */ p.k_M = p43[32];
+    p.conc_TDPs_A = p43[33]; p.conc_TDPs_NC = p43[34]; p.PlabA_i = p43[35]; p.PlabNC_i = p43[36];
+    p.Msoil = p43[37]; p.TDPeff = p43[38]; p.TDPg = p43[39]; p.E_PP = p43[40]; p.P_inactive = p43[41];
+    p.Qg_min = p43[42];
+    ode_f(y12, &p, dy12);
+}

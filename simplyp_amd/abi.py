@@ -1,0 +1,60 @@
+"""ctypes mirror of include/simplyp.h (structs, enums, default options)."""
+
+import ctypes as C
+
+ABI_VERSION = 1
+
+INTEG_RK4 = 0
+INTEG_CASHKARP = 1
+INTEGRATORS = {'rk4': INTEG_RK4, 'cashkarp': INTEG_CASHKARP, 'ck45': INTEG_CASHKARP}
+
+STATUS_NONFINITE = 1
+STATUS_STEPCAP = 2
+
+
+class Dims(C.Structure):
+    _fields_ = [('E', C.c_int32), ('S', C.c_int32), ('D', C.c_int32), ('n_forcing_sets', C.c_int32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [('integrator', C.c_int32), ('substeps', C.c_int32),
+                ('rtol', C.c_double), ('atol', C.c_double),
+                ('max_steps', C.c_int32), ('dynamic_epc0', C.c_int32), ('dynamic_erod', C.c_int32),
+                ('run_mode_cal', C.c_int32), ('sc_qr0', C.c_int32), ('out_mask', C.c_uint32),
+                ('step_len', C.c_double), ('reserved0', C.c_int32), ('reserved1', C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [('rhs_evals', C.c_uint64), ('steps', C.c_uint64), ('rejected', C.c_uint64),
+                ('kernel_ms', C.c_double), ('n_launches', C.c_int32), ('reserved', C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}
+
+
+# Solver settings used when the caller does not choose: Cash-Karp 5(4) with per-thread step
+# control at the tolerance that meets the <= 1e-6 parity bar against odeint(rtol=atol=1e-12)
+# ("Integrator").
+DEFAULT_SOLVER = dict(integrator='cashkarp', substeps=8, rtol=1e-8, atol=1e-10, max_steps=4000)
+
+
+def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=True, sc_qr0=0,
+              out_mask=(1 << 25) - 1, step_len=1.0):
+    s = dict(DEFAULT_SOLVER)
+    s.update(solver or {})
+    integ = s['integrator']
+    if isinstance(integ, str):
+        integ = INTEGRATORS[integ.lower()]
+    o = Opts()
+    o.integrator = int(integ)
+    o.substeps = int(s['substeps'])
+    o.rtol = float(s['rtol'])
+    o.atol = float(s['atol'])
+    o.max_steps = int(s['max_steps'])
+    o.dynamic_epc0 = int(bool(dynamic_epc0))
+    o.dynamic_erod = int(bool(dynamic_erod))
+    o.run_mode_cal = int(bool(run_mode_cal))
+    o.sc_qr0 = int(sc_qr0)
+    o.out_mask = int(out_mask)
+    o.step_len = float(step_len)
+    return o

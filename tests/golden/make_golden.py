@@ -1,0 +1,375 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the *unmodified* reference.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes
+are data (inputs + expected outputs) and are what travels to the GPU box.
+
+How the reference is driven:
+  * its three source modules (helper_functions.py, inputs.py, model.py) are compiled from
+    their source text into a stand-in package ``simplyP`` (the package __init__ imports
+    seaborn, which is not installed; the cached .pyc files are not used);
+  * removed numpy/pandas APIs it calls are shimmed: ``np.NaN``, ``DataFrame.ix``,
+    ``Series.ix``;
+  * the workbook is parsed by simplyp_amd.xlsx (no Excel engine exists here);
+  * ``odeint`` as seen by model.py is wrapped so the same call site (model.py:640) can be run
+    either as shipped (rtol=0.01, default atol, mxstep=5000) or at rtol=atol=1e-12
+    ("tight": the converged solution of the reference's own equations = the parity oracle).
+
+Usage:  python tests/golden/make_golden.py [--long]
+"""
+
+import argparse
+import copy
+import io
+import json
+import os
+import sys
+import time
+import types
+import contextlib
+
+import numpy as np
+import pandas as pd
+import scipy.integrate
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+REF_PKG = os.path.join(REF, 'Current_Release', 'v0-2A', 'simplyP')
+sys.path.insert(0, REPO)
+
+
+# ----------------------------------------------------------------------------------------
+# reference loader + shims
+
+class _Ix(object):
+    """Stand-in for the removed ``.ix`` indexer: integer row keys are positions when the
+    index is not integer-typed (as in pandas < 1.0), everything else is label based."""
+
+    def __init__(self, obj):
+        self.obj = obj
+
+    def _split(self, key):
+        obj = self.obj
+        if isinstance(obj, pd.DataFrame) and isinstance(key, tuple):
+            r, c = key
+            if isinstance(r, (int, np.integer)) and not pd.api.types.is_integer_dtype(obj.index):
+                return ('iloc', (r, obj.columns.get_loc(c)))
+            return ('loc', key)
+        if isinstance(key, (int, np.integer)) and not pd.api.types.is_integer_dtype(obj.index):
+            return ('iloc', key)
+        return ('loc', key)
+
+    def __getitem__(self, key):
+        how, k = self._split(key)
+        return getattr(self.obj, how)[k]
+
+    def __setitem__(self, key, value):
+        how, k = self._split(key)
+        getattr(self.obj, how)[k] = value
+
+
+def load_reference():
+    if not hasattr(np, 'NaN'):
+        np.NaN = np.nan
+    pd.DataFrame.ix = property(lambda self: _Ix(self))
+    pd.Series.ix = property(lambda self: _Ix(self))
+    pkg = types.ModuleType('simplyP')
+    pkg.__path__ = [REF_PKG]
+    sys.modules['simplyP'] = pkg
+    mods = {}
+    for name in ('helper_functions', 'inputs', 'model'):
+        path = os.path.join(REF_PKG, name + '.py')
+        mod = types.ModuleType('simplyP.' + name)
+        mod.__file__ = path
+        sys.modules['simplyP.' + name] = mod
+        setattr(pkg, name, mod)
+        with open(path) as fh:
+            code = compile(fh.read(), path, 'exec')
+        exec(code, mod.__dict__)
+        mods[name] = mod
+    return mods
+
+
+class OdeintSwitch(object):
+    """Replaces ``model.odeint``; forwards to SciPy with either the caller's tolerances
+    (as shipped) or rtol=atol=tight."""
+
+    def __init__(self):
+        self.tight = None
+        self.nfe = 0
+        self.calls = 0
+
+    def __call__(self, func, y0, t, args=(), full_output=0, rtol=None, mxstep=0, **kw):
+        if self.tight is None:
+            out = scipy.integrate.odeint(func, y0, t, args=args, full_output=full_output,
+                                         rtol=rtol, mxstep=mxstep, **kw)
+        else:
+            out = scipy.integrate.odeint(func, y0, t, args=args, full_output=full_output,
+                                         rtol=self.tight, atol=self.tight, mxstep=100000, **kw)
+        if full_output:
+            self.nfe += int(out[1]['nfe'][-1])
+            self.calls += 1
+        return out
+
+
+# ----------------------------------------------------------------------------------------
+# scenarios
+
+def tarland_inputs(st_dt, end_dt):
+    """The shipped Tarland workbook + met file, truncated to [st_dt, end_dt]; snow via the
+    reference's own snow_hydrol_inputs is applied later by the caller."""
+    from simplyp_amd import xlsx
+    wbp = os.path.join(REF, 'Current_Release', 'v0-2A', 'Parameters_v0-2A_Tarland.xlsx')
+    wb = xlsx.Workbook(wbp)
+    p_SU = xlsx.read_excel(wb, 'Setup', index_col=0, usecols="A,C")['Value']
+    p = xlsx.read_excel(wb, 'Constant', index_col=0, usecols="B,E")['Value'].astype(object)
+    p_LU = xlsx.read_excel(wb, 'LU', index_col=0, usecols="B,E,F,G,H").astype(float)
+    p_SC = xlsx.read_excel(wb, 'SC_reach', index_col=0, usecols="B,E").astype(float)
+    p_struc = xlsx.read_excel(wb, 'Reach_structure', index_col=0, usecols="A,B,C")
+    p_struc.columns = ['Upstream_SCs', 'In_final_flux?']
+    p['SC_list'] = np.arange(1, 2)
+    p_SU = p_SU.copy()
+    p_SU['st_dt'], p_SU['end_dt'] = st_dt, end_dt
+    met = pd.read_csv(os.path.join(REF, 'Example_Data', 'Tarland_Scotland', 'Tarland_MetData_1981-2010.csv'),
+                      parse_dates=True, dayfirst=True, index_col=0)
+    met = met.truncate(before=st_dt, after=end_dt)
+    return p_SU, p, p_LU, p_SC, p_struc, met
+
+
+def make_multi_reach(p, p_SC, p_struc, cols, upstream, final_flux):
+    """Widen the 1-SC Tarland tables to len(cols) sub-catchments; ``cols`` is a list of dicts
+    overriding SC_reach rows per sub-catchment."""
+    n = len(cols)
+    base = p_SC[1]
+    new = pd.DataFrame({i + 1: base.copy() for i in range(n)})
+    for i, over in enumerate(cols):
+        for k, v in over.items():
+            new.loc[k, i + 1] = v
+    p = p.copy()
+    p['SC_list'] = np.arange(1, n + 1)
+    struc = pd.DataFrame({'Upstream_SCs': pd.Series(upstream, index=range(1, n + 1), dtype=object),
+                          'In_final_flux?': pd.Series(final_flux, index=range(1, n + 1))})
+    struc.index.name = 'Reach'
+    return p, new, struc
+
+
+def scenarios(long_run):
+    """name -> dict(inputs...).  Every scenario is the Tarland workbook plus explicit edits."""
+    out = {}
+
+    def base(st, en):
+        p_SU, p, p_LU, p_SC, p_struc, met = tarland_inputs(st, en)
+        return dict(p_SU=p_SU, p=p, p_LU=p_LU, p_SC=p_SC, p_struc=p_struc, met=met,
+                    dyn=dict(Dynamic_EPC0='n', Dynamic_erodibility='n'))
+
+    # 1. exactly as shipped (BASELINE config C1)
+    out['tarland_2004_static'] = base('2004-01-01', '2004-12-31')
+
+    # 2. both dynamic options on (the setting the shipped Example_Output CSVs were made with)
+    s = base('2004-01-01', '2004-12-31')
+    s['dyn'] = dict(Dynamic_EPC0='y', Dynamic_erodibility='y')
+    out['tarland_2004_dynamic'] = s
+
+    # 3. confluence 1,2 -> 3 with newly-converted land of both kinds; last SC is type 'S'
+    s = base('2004-01-01', '2004-12-31')
+    s['dyn'] = dict(Dynamic_EPC0='y', Dynamic_erodibility='y')
+    s['p'], s['p_SC'], s['p_struc'] = make_multi_reach(
+        s['p'], s['p_SC'], s['p_struc'],
+        [dict(A_catch=21.3, f_Ar=0.25, f_IG=0.25, f_S=0.5, L_reach=6200., S_reach=1.4, S_Ar=3., TDPeff=0.02),
+         dict(A_catch=30.4, f_Ar=0.125, f_IG=0.375, f_S=0.5, f_NC_Ar=0.2, L_reach=8100., S_reach=0.9,
+              f_spr=0.4, TDPeff=np.nan),
+         dict(A_catch=51.7, f_Ar=0.2, f_IG=0.3, f_S=0.5, f_NC_S=0.15, L_reach=4000., S_reach=0.5, TDPeff=0.1)],
+        upstream=[np.nan, np.nan, '1, 2'], final_flux=[0, 0, 1])
+    s['p_SU'] = s['p_SU'].copy(); s['p_SU']['n_SC'] = 3
+    s['p']['SC_Qr0'] = 3.0
+    out['confluence3_nc_2004'] = s
+
+    # 4. 4-reach chain, validation mode (Kf from the sheet), Qg_min = 0 (threshold-0 gate),
+    #    non-integer d_maxE_aut (erosion-window membership test never true for autumn)
+    s = base('2004-01-01', '2004-12-31')
+    s['dyn'] = dict(Dynamic_EPC0='y', Dynamic_erodibility='y')
+    s['p'], s['p_SC'], s['p_struc'] = make_multi_reach(
+        s['p'], s['p_SC'], s['p_struc'],
+        [dict(A_catch=8.5, f_Ar=0.5, f_IG=0.25, f_S=0.25, L_reach=3000., S_reach=2.5, S_SN=12.),
+         dict(A_catch=12.25, f_Ar=0.25, f_IG=0.25, f_S=0.5, L_reach=5000., S_reach=1.5, f_NC_IG=0.3),
+         dict(A_catch=20.0, f_Ar=0.125, f_IG=0.125, f_S=0.75, L_reach=7000., S_reach=1.0, TDPeff=0.5),
+         dict(A_catch=51.7, f_Ar=0.2, f_IG=0.3, f_S=0.5, L_reach=10000., S_reach=0.8, f_NC_Ar=0.1)],
+        upstream=[np.nan, 1, 2, 3], final_flux=[0, 0, 0, 1])
+    s['p_SU'] = s['p_SU'].copy(); s['p_SU']['n_SC'] = 4; s['p_SU']['run_mode'] = 'val'
+    s['p']['SC_Qr0'] = 4.0
+    s['p']['Qg_min'] = 0.0
+    s['p']['d_maxE_aut'] = 304.5
+    s['p']['k_M'] = 1.7
+    out['chain4_val_2004'] = s
+
+    if long_run:
+        s = base('1981-01-01', '2010-12-31')
+        s['dyn'] = dict(Dynamic_EPC0='y', Dynamic_erodibility='y')
+        out['tarland_1981_2010_dynamic'] = s
+    return out
+
+
+def run_reference(mods, switch, sc, tight):
+    model, inputs = mods['model'], mods['inputs']
+    p_SU, p, p_LU, p_SC, p_struc = (copy.deepcopy(sc[k]) for k in ('p_SU', 'p', 'p_LU', 'p_SC', 'p_struc'))
+    met = sc['met'].copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        met = inputs.snow_hydrol_inputs(p['D_snow_0'], p['f_DDSM'], met)
+    dyn = pd.Series(dict(sc['dyn'], Dynamic_effluent_inputs='n', Dynamic_terrestrialP_inputs='n'))
+    switch.tight, switch.nfe, switch.calls = tight, 0, 0
+    t0 = time.time()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), np.errstate(all='ignore'):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            df_TC, df_R, Kf, od = model.run_simply_p(met, p_struc, p_SU, p_LU, p_SC, p, dyn)
+    wall = time.time() - t0
+    return dict(df_TC=df_TC, df_R=df_R, Kf=Kf, met=met, p_LU=p_LU, p_SC=p_SC, wall=wall,
+                nfe_per_day=switch.nfe / max(switch.calls, 1), stdout=buf.getvalue())
+
+
+def scenario_json(sc):
+    """Inputs of a scenario as plain JSON (what the tests rebuild pandas objects from)."""
+    def clean(v):
+        if isinstance(v, (np.integer,)):
+            return int(v)
+        if isinstance(v, (float, np.floating)):
+            return None if np.isnan(v) else float(v)
+        if isinstance(v, np.ndarray):
+            return [clean(x) for x in v]
+        return v
+    return dict(
+        p_SU={k: clean(v) for k, v in sc['p_SU'].items()},
+        p={k: clean(v) for k, v in sc['p'].items()},
+        p_LU={c: {k: clean(v) for k, v in sc['p_LU'][c].items()} for c in sc['p_LU'].columns},
+        p_SC={str(c): {k: clean(v) for k, v in sc['p_SC'][c].items()} for c in sc['p_SC'].columns},
+        p_struc={str(i): {k: clean(v) for k, v in row.items()} for i, row in sc['p_struc'].iterrows()},
+        dyn=sc['dyn'])
+
+
+def unit_vectors(mods, rng):
+    """In/out pairs of the three exported scalar functions (model.py:23, :39, :58)."""
+    model = mods['model']
+    out = {}
+    # f_x: both sides of, and inside, the activation interval; threshold 0
+    xs, ths, ys = [], [], []
+    for th in (290.0, 0.4, 1e-3, 0.0):
+        d = th * 0.01
+        for x in [th - 1.0, th - 1e-9, th, th + 0.25 * d, th + 0.5 * d, th + 0.999 * d, th + d, th + d + 1e-9, th + 5.0]:
+            if th == 0.0 and x == 0.0:
+                continue      # 0/0 in the reference
+            xs.append(x); ths.append(th); ys.append(float(model.f_x(x, th, 0.01)))
+    out['fx_x'], out['fx_th'], out['fx_y'] = map(np.array, (xs, ths, ys))
+
+    # discretized_soilP
+    n = 64
+    P_net = rng.uniform(0, 30, n); A = rng.uniform(5, 60, n); Kf = rng.uniform(5e-5, 3e-4, n)
+    Msoil = 95e6 * A; EPC0 = rng.uniform(0, 8, n); Qs = rng.uniform(0, 6, n); Qq = rng.uniform(0, 1.5, n)
+    Vs = rng.uniform(80, 330, n); TDPs = rng.uniform(0, 2500, n); Plab = rng.uniform(0, 4e6, n)
+    Vs[:3] = 0.0   # the Vs>0 guard (model.py:50); TDPs becomes nan/inf there as in the reference
+    res = []
+    with np.errstate(all='ignore'):
+        for i in range(n):
+            res.append(model.discretized_soilP(P_net[i], A[i], 1, Kf[i], Msoil[i], EPC0[i], Qs[i], Qq[i],
+                                               Vs[i], TDPs[i], Plab[i]))
+    out['sp_in'] = np.stack([P_net, A, Kf, Msoil, EPC0, Qs, Qq, Vs, TDPs, Plab], axis=1)
+    out['sp_out'] = np.array(res, dtype=float)
+
+    # ode_f: random physically valid states x parameter draws, all NC types, both gate sides
+    n = 96
+    ys_in, ps_in, dys = [], [], []
+    for i in range(n):
+        fc = rng.uniform(200, 350)
+        where = i % 4
+        def soil():
+            if where == 0: return fc - rng.uniform(0, 150)
+            if where == 1: return fc + rng.uniform(0, 0.01 * fc)
+            return fc + 0.01 * fc + rng.uniform(0, 40)
+        T_g = rng.uniform(30, 130); Qg_min = [0.4, 0.0, 0.25, 0.6][i % 4]
+        Vg = T_g * (Qg_min + rng.uniform(-0.2, 1.5)) if i % 3 else T_g * Qg_min * (1 + 0.01 * rng.uniform(0, 1))
+        Vg = max(Vg, 1.0)
+        y = [soil(), soil(), Vg, rng.uniform(0.1, 3), rng.uniform(0.3, 9), 0.0, rng.uniform(0, 5e3), 0.0,
+             rng.uniform(0, 20), 0.0, rng.uniform(0, 30), 0.0]
+        f_Ar, f_IG = rng.uniform(0.05, 0.4), rng.uniform(0.05, 0.4); f_S = 1 - f_Ar - f_IG; f_A = f_Ar + f_IG
+        nc = ['None', 'A', 'S'][i % 3]
+        f_NC_Ar = rng.uniform(0, 0.5) if nc == 'A' else 0.0
+        f_NC_IG = rng.uniform(0, 0.5) if nc == 'A' else 0.0
+        f_NC_S = rng.uniform(0, 0.5) if nc == 'S' else 0.0
+        f_NC_A = f_Ar * f_NC_Ar + f_NC_IG * f_IG
+        P, E = rng.uniform(0, 40), rng.uniform(0, 4)
+        f_quick = rng.uniform(0.0, 0.1)
+        A_catch = rng.uniform(5, 60); Msoil = 95e6 * A_catch
+        Esus = rng.uniform(50, 5000, 3)
+        num = [P, E, -np.log(0.01) / fc, f_quick * P, rng.uniform(0, 3) * (i % 2), Esus[0], Esus[1], Esus[2],
+               rng.uniform(0, 2e3) * (i % 2), rng.uniform(0, 5) * (i % 2), rng.uniform(0, 9) * (i % 2),
+               f_A, f_Ar, f_IG, f_S, f_NC_A, f_NC_Ar, f_NC_IG, f_NC_S, ['None', 'A', 'S'].index(nc),
+               f_quick, rng.uniform(0.7, 1.1), rng.uniform(0.4, 0.9), rng.uniform(1, 6), rng.uniform(5, 20), T_g, fc,
+               rng.uniform(2e3, 15e3), A_catch, rng.uniform(0.25, 1.0), rng.uniform(0.3, 0.5), 1500.0,
+               rng.uniform(1.5, 2.5), rng.uniform(0, 8), rng.uniform(0, 8), rng.uniform(0, 4e6), rng.uniform(0, 4e6),
+               Msoil, rng.uniform(0, 1), rng.uniform(0, 0.05), rng.uniform(1, 2), 873e-6 * Msoil, Qg_min]
+        (P, E, mu, Qq, Qr_US, EsA, EsS, EsIG, Msus_US, TDPr_US, PPr_US, f_A, f_Ar, f_IG, f_S, f_NC_A, f_NC_Ar,
+         f_NC_IG, f_NC_S, nci, f_quick, alpha, beta, TsA, TsS, T_g, fc, L, A_catch, a_Q, b_Q, E_M, k_M, cA, cNC,
+         PlabA, PlabNC, Msoil, TDPeff, TDPg, E_PP, P_inact, Qg_min) = num
+        params = [P, E, mu, Qq, Qr_US, pd.Series([EsA, EsS, EsIG], ['A', 'S', 'IG']), Msus_US, TDPr_US, PPr_US,
+                  f_A, f_Ar, f_IG, f_S, f_NC_A, f_NC_Ar, f_NC_IG, f_NC_S, nc, f_quick, alpha, beta,
+                  pd.Series([TsA, TsS], ['A', 'S']), T_g, fc, L, A_catch, a_Q, b_Q, E_M, k_M, cA, cNC, PlabA, PlabNC,
+                  Msoil, TDPeff, TDPg, E_PP, P_inact, 'y', Qg_min]
+        dy = model.ode_f(np.array(y), 0.0, params)
+        ys_in.append(y); ps_in.append(num); dys.append(np.asarray(dy, dtype=float))
+    out['ode_y'] = np.array(ys_in); out['ode_p'] = np.array(ps_in, dtype=float); out['ode_dy'] = np.array(dys)
+    out['ode_p_names'] = np.array(
+        'P E mu Qq Qr_US Esus_A Esus_S Esus_IG Msus_US TDPr_US PPr_US f_A f_Ar f_IG f_S f_NC_A f_NC_Ar f_NC_IG '
+        'f_NC_S NC_type f_quick alpha beta T_s_A T_s_S T_g fc L_reach A_catch a_Q b_Q E_M k_M conc_TDPs_A '
+        'conc_TDPs_NC Plab_A Plab_NC Msoil TDPeff TDPg E_PP P_inactive Qg_min'.split())
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--long', action='store_true', help='also run the 1981-2010 scenario (minutes)')
+    ap.add_argument('--only', default=None)
+    args = ap.parse_args()
+
+    mods = load_reference()
+    switch = OdeintSwitch()
+    mods['model'].odeint = switch
+    rng = np.random.default_rng(20240601)
+
+    if args.only in (None, 'unit'):
+        np.savez_compressed(os.path.join(HERE, 'unit_vectors.npz'), **unit_vectors(mods, rng))
+        print('unit_vectors.npz written')
+
+    meta_path = os.path.join(HERE, 'series_meta.json')
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    for name, sc in scenarios(args.long).items():
+        if args.only not in (None, name):
+            continue
+        arrays = {}
+        info = dict(inputs=scenario_json(sc), runs={})
+        for label, tight in (('shipped', None), ('tight', 1e-12)):
+            r = run_reference(mods, switch, sc, tight)
+            for SC in r['df_R']:
+                arrays['%s/R%d/columns' % (label, SC)] = np.array(list(r['df_R'][SC].columns))
+                arrays['%s/R%d' % (label, SC)] = r['df_R'][SC].to_numpy(dtype=float)
+                arrays['%s/TC%d/columns' % (label, SC)] = np.array(list(r['df_TC'][SC].columns))
+                arrays['%s/TC%d' % (label, SC)] = r['df_TC'][SC].to_numpy(dtype=float)
+            info['runs'][label] = dict(Kf=float(r['Kf']), wall_s=r['wall'], nfe_per_day=r['nfe_per_day'],
+                                       stdout=r['stdout'])
+            print('%-28s %-8s wall %.1f s  nfe/day %.1f' % (name, label, r['wall'], r['nfe_per_day']))
+        met = r['met']
+        arrays['met/index'] = np.array([d.strftime('%Y-%m-%d') for d in met.index])
+        arrays['met/columns'] = np.array(list(met.columns))
+        arrays['met/values'] = met.to_numpy(dtype=float)
+        info['p_LU_after'] = {c: {k: (None if pd.isna(v) else float(v)) for k, v in r['p_LU'][c].items()}
+                              for c in r['p_LU'].columns}
+        info['p_SC_after'] = {str(c): {k: (v if isinstance(v, str) else (None if pd.isna(v) else float(v)))
+                                       for k, v in r['p_SC'][c].items()} for c in r['p_SC'].columns}
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), **arrays)
+        meta[name] = info
+        json.dump(meta, open(meta_path, 'w'), indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,88 @@
+"""Shared test helpers: rebuild the reference-shaped pandas inputs of a golden scenario,
+and compare result tables."""
+
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+_meta = None
+
+
+def meta():
+    global _meta
+    if _meta is None:
+        with open(os.path.join(GOLDEN, 'series_meta.json')) as fh:
+            _meta = json.load(fh)
+    return _meta
+
+
+def _nan(v):
+    return np.nan if v is None else v
+
+
+def scenario_inputs(name):
+    """(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options) exactly as the golden run got them."""
+    info = meta()[name]['inputs']
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    met = pd.DataFrame(z['met/values'], columns=[str(c) for c in z['met/columns']],
+                       index=pd.to_datetime([str(d) for d in z['met/index']]))
+    met.index.name = 'Date'
+    p_SU = pd.Series({k: _nan(v) for k, v in info['p_SU'].items()}, dtype=object)
+    pd_ = {k: _nan(v) for k, v in info['p'].items()}
+    pd_['SC_list'] = np.asarray(pd_['SC_list'])
+    p = pd.Series(pd_, dtype=object)
+    p_LU = pd.DataFrame({c: {k: _nan(v) for k, v in col.items()} for c, col in info['p_LU'].items()}, dtype=float)
+    p_LU = p_LU[['A', 'S', 'IG', 'NC']]
+    p_SC = pd.DataFrame({int(c): {k: _nan(v) for k, v in col.items()} for c, col in info['p_SC'].items()}, dtype=float)
+    rows = {int(i): {k: _nan(v) for k, v in row.items()} for i, row in info['p_struc'].items()}
+    p_struc = pd.DataFrame.from_dict(rows, orient='index')
+    p_struc['Upstream_SCs'] = p_struc['Upstream_SCs'].astype(object)
+    p_struc.index.name = 'Reach'
+    dyn = pd.Series(dict(info['dyn'], Dynamic_effluent_inputs='n', Dynamic_terrestrialP_inputs='n'))
+    return met, p_struc, p_SU, p_LU, p_SC, p, dyn
+
+
+def golden_tables(name, label):
+    """{'R': {SC: DataFrame}, 'TC': {SC: DataFrame}} of the golden run `label` ('tight' | 'shipped')."""
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    idx = pd.to_datetime([str(d) for d in z['met/index']])
+    out = {'R': {}, 'TC': {}}
+    for key in z.files:
+        parts = key.split('/')
+        if parts[0] != label or len(parts) != 2:
+            continue
+        kind = 'R' if parts[1].startswith('R') else 'TC'
+        sc = int(parts[1][len(kind):])
+        out[kind][sc] = pd.DataFrame(z[key], columns=[str(c) for c in z[key + '/columns']], index=idx)
+    return out
+
+
+def max_rel_err(a, b, floor=0.0):
+    """max over elements of |a-b| / max(|b|, floor); NaN-in-both counts as equal."""
+    a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
+    both_nan = np.isnan(a) & np.isnan(b)
+    denom = np.maximum(np.abs(b), floor)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        r = np.abs(a - b) / denom
+    r = np.where((a == b) | both_nan, 0.0, r)
+    return float(np.nanmax(r)) if r.size else 0.0
+
+
+def marshal_scenario(name, E=1, out_mask=None, solver=None):
+    """Arrays + opts for engine/oracle `run` from a golden scenario (base parameters replicated E times)."""
+    from simplyp_amd import marshal, abi
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = scenario_inputs(name)
+    marshal.prologue(p_SU, p_LU, p_SC, p)
+    up_ptr, up_idx, _ = marshal.topology(p_struc, p)
+    mp = marshal.member_params(p, p_LU, E)
+    rp = marshal.reach_params(p_SC, p, E)
+    forcing, doy = marshal.forcing_arrays(met)
+    scs = marshal.sc_list(p)
+    opts = abi.make_opts(solver, dynamic_epc0=dyn['Dynamic_EPC0'] == 'y', dynamic_erod=dyn['Dynamic_erodibility'] == 'y',
+                         run_mode_cal=p_SU.run_mode == 'cal', sc_qr0=scs.index(int(p['SC_Qr0'])),
+                         out_mask=marshal.MASK_ALL if out_mask is None else out_mask)
+    return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx, opts=opts,
+                scs=scs, met=met)
