@@ -104,7 +104,8 @@ typedef struct {
     int32_t  sc_qr0;         /* zero-based reach that Qr0_init refers to (p['SC_Qr0']-1, model.py:386) */
     uint32_t out_mask;       /* bit c set -> column c (SIMPLYP_OUT_*) is written           */
     double   step_len;       /* integration span per day, model.py:345 (default 1.0)       */
-    int32_t  reserved0;
+    int32_t  project_vr;     /* 1: at each day end reset Vr to the invariant of the reference's own equations,
+                                L_reach*Qr^(1-b_Q)/(a_Q*86400) (drift control; 0 = integrate Vr literally) */
     int32_t  reserved1;
 } simplyp_opts;
 
@@ -128,6 +129,9 @@ int  simplyp_device_count(void);
 int  simplyp_ctx_create(int device, simplyp_ctx** out);
 void simplyp_ctx_destroy(simplyp_ctx* ctx);
 const char* simplyp_last_error(const simplyp_ctx* ctx);   /* ctx may be NULL: create errors */
+/* Run on the caller's stream (a hipStream_t passed as void*, e.g. torch.cuda.current_stream()
+ * .cuda_stream) so the launches order with the caller's own copies; NULL = a private stream. */
+int  simplyp_ctx_set_stream(simplyp_ctx* ctx, void* hip_stream);
 
 /* Bytes of `out` that simplyp_run will write: popcount(out_mask) * D * n_out_reaches * E * 8. */
 int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, int32_t n_out_reaches);
@@ -159,6 +163,18 @@ int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* 
                 const int32_t* up_ptr, const int32_t* up_idx,
                 const int32_t* out_reaches, int32_t n_out_reaches,
                 double* out, int32_t* member_status, simplyp_stats* stats);
+
+/*
+ * simplyp_plan -- the routing schedule simplyp_run will use for a reach graph, without touching a
+ * device (host-only; also what the CPU tests check).  Reaches are grouped into launches; inside a
+ * launch each chain is walked by one thread per member, upstream to downstream.
+ *   launch_of_reach, chain_of_reach, pos_in_chain, route_slot : host [S] outputs (any may be NULL);
+ *   route_slot[s] = slot of the routing buffer that carries reach s's daily series downstream, -1
+ *   when no reach reads it.  n_launches / n_slots: totals.
+ */
+int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx,
+                 int32_t* n_launches, int32_t* n_slots,
+                 int32_t* launch_of_reach, int32_t* chain_of_reach, int32_t* pos_in_chain, int32_t* route_slot);
 
 /* Same as simplyp_run but only enqueues on the context's stream (for overlap with the
  * caller's own copies); simplyp_sync() waits and fills `stats`. */

@@ -131,7 +131,7 @@ static void ode_f(const double* y, const ode_params* p, double* dy)
 
 #define NY 12
 
-typedef struct { uint64_t rhs, steps, rejected; int capped; } integ_stats;
+typedef struct { uint64_t rhs, steps, rejected; int capped, poisoned; } integ_stats;
 
 static void rk4_day(double* y, const ode_params* p, double T, int n, integ_stats* st)
 {
@@ -149,96 +149,87 @@ static void rk4_day(double* y, const ode_params* p, double T, int n, integ_stats
     st->rhs += 4u * (uint64_t)n; st->steps += (uint64_t)n;
 }
 
-/* Embedded explicit RK pair described by a Butcher tableau (up to 7 stages). */
-typedef struct {
-    int stages, fsal, order;        /* order = order of the propagated solution */
-    double c[7], a[7][6], b[7], e[7];   /* e = b - bhat (error weights) */
-} tableau;
+/* Cash-Karp 5(4) embedded pair (Cash & Karp, ACM TOMS 16 (1990) 201-222). */
+static const double CK_A[6][5] = {
+    {0},
+    {1.0 / 5},
+    {3.0 / 40, 9.0 / 40},
+    {3.0 / 10, -9.0 / 10, 6.0 / 5},
+    {-11.0 / 54, 5.0 / 2, -70.0 / 27, 35.0 / 27},
+    {1631.0 / 55296, 175.0 / 512, 575.0 / 13824, 44275.0 / 110592, 253.0 / 4096}};
+static const double CK_B[6] = {37.0 / 378, 0, 250.0 / 621, 125.0 / 594, 0, 512.0 / 1771};
+static const double CK_E[6] = {37.0 / 378 - 2825.0 / 27648, 0, 250.0 / 621 - 18575.0 / 48384,
+                               125.0 / 594 - 13525.0 / 55296, -277.0 / 14336, 512.0 / 1771 - 1.0 / 4};   /* b - bhat */
 
-static const tableau CASH_KARP = {
-    6, 0, 5,
-    {0, 1.0 / 5, 3.0 / 10, 3.0 / 5, 1.0, 7.0 / 8, 0},
-    {{0},
-     {1.0 / 5},
-     {3.0 / 40, 9.0 / 40},
-     {3.0 / 10, -9.0 / 10, 6.0 / 5},
-     {-11.0 / 54, 5.0 / 2, -70.0 / 27, 35.0 / 27},
-     {1631.0 / 55296, 175.0 / 512, 575.0 / 13824, 44275.0 / 110592, 253.0 / 4096},
-     {0}},
-    {37.0 / 378, 0, 250.0 / 621, 125.0 / 594, 0, 512.0 / 1771, 0},
-    {37.0 / 378 - 2825.0 / 27648, 0, 250.0 / 621 - 18575.0 / 48384, 125.0 / 594 - 13525.0 / 55296,
-     -277.0 / 14336, 512.0 / 1771 - 1.0 / 4, 0}
-};
-
-/* Dormand-Prince 5(4) -- experimental comparison scheme (integrator id 2), not in the ABI. */
-static const tableau DOPRI5 = {
-    7, 1, 5,
-    {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0},
-    {{0},
-     {1.0 / 5},
-     {3.0 / 40, 9.0 / 40},
-     {44.0 / 45, -56.0 / 15, 32.0 / 9},
-     {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
-     {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
-     {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}},
-    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0},
-    {35.0 / 384 - 5179.0 / 57600, 0, 500.0 / 1113 - 7571.0 / 16695, 125.0 / 192 - 393.0 / 640,
-     -2187.0 / 6784 + 92097.0 / 339200, 11.0 / 84 - 187.0 / 2100, -1.0 / 40}
-};
+static int state_finite(const double* y)
+{   /* the 8 carried states (slots 0-4, 6, 8, 10) */
+    static const int idx[8] = {0, 1, 2, 3, 4, 6, 8, 10};
+    for (int i = 0; i < 8; ++i) if (!(fabs(y[idx[i]]) < 1.0e300)) return 0;
+    return 1;
+}
 
 /*
- * Adaptive step control -- the exact rule the device kernel mirrors:
- *   trial step hh = h, except  rem <= 1.1 h -> hh = rem;  rem < 2 h -> hh = rem/2   (rem = T - t)
- *   err = max_i |e_i| / (atol + rtol * max(|y_i|, |ynew_i|))
- *   accept iff err <= 1 (or the step cap was hit, or hh <= 1e-9 T: forced)
- *   h <- hh * clamp(0.9 * err^(-1/5), 0.2, 5)      (err == 0 -> 5; non-finite err -> 0.2)
+ * Adaptive step control -- the exact rule the device kernel implements (ck_day in
+ * simplyp_amd/csrc/simplyp_kernels.hip.h):
+ *   a day whose start state is non-finite is not integrated (member poisoned);
+ *   trial step hh = h, except  rem <= 1.1 h -> hh = rem;  rem < 2 h -> hh = rem/2   (rem = T - t);
+ *   the max_steps-th attempt of a day takes hh = rem and is accepted whatever its error (STEPCAP);
+ *   err = max_i |hh e_i| / (atol + rtol * max(|y_i|, |ynew_i|)) over all 12 components;
+ *   a non-finite trial is rejected with factor 0.2; at hh <= 1e-9 T (or on the last attempt) the
+ *   member is poisoned (state := NaN) instead;
+ *   accept iff err <= 1;  h <- hh * clamp(0.9 * err^(-1/5), 0.2, 5)   (err == 0 -> 5);
  *   *h_carry (the controller's h) persists from day to day.
  */
-static void embedded_day(const tableau* tb, double* y, const ode_params* p, double T, double rtol, double atol,
+static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, double atol,
                          int max_steps, double* h_carry, integ_stats* st)
 {
-    double k[7][NY], yt[NY], yn[NY];
+    double k[6][NY], yt[NY], yn[NY];
     double t = 0.0, h = *h_carry;
-    int attempts = 0, have_k1 = 0;
+    int attempts = 0;
     if (!(h > 0.0) || h > T) h = T;
+    if (!state_finite(y)) { y[5] = y[7] = y[9] = y[11] = NAN; st->poisoned = 1; return; }
     while (t < T) {
         double rem = T - t, hh = h;
         if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
-        if (!have_k1) { ode_f(y, p, k[0]); st->rhs++; }
-        for (int s = 1; s < tb->stages; ++s) {
+        int last_chance = (attempts + 1 >= max_steps);
+        if (last_chance) hh = rem;
+        ode_f(y, p, k[0]);
+        for (int s = 1; s < 6; ++s) {
             for (int i = 0; i < NY; ++i) {
                 double acc = 0.0;
-                for (int j = 0; j < s; ++j) acc += tb->a[s][j] * k[j][i];
+                for (int j = 0; j < s; ++j) acc += CK_A[s][j] * k[j][i];
                 yt[i] = y[i] + hh * acc;
             }
-            ode_f(yt, p, k[s]); st->rhs++;
+            ode_f(yt, p, k[s]);
         }
+        st->rhs += 6;
         double err = 0.0; int bad = 0;
         for (int i = 0; i < NY; ++i) {
             double inc = 0.0, ee = 0.0;
-            for (int s = 0; s < tb->stages; ++s) { inc += tb->b[s] * k[s][i]; ee += tb->e[s] * k[s][i]; }
+            for (int s = 0; s < 6; ++s) { inc += CK_B[s] * k[s][i]; ee += CK_E[s] * k[s][i]; }
             yn[i] = y[i] + hh * inc;
             double sc = atol + rtol * fmax(fabs(y[i]), fabs(yn[i]));
             double r = fabs(hh * ee) / sc;
-            if (!isfinite(r)) bad = 1; else if (r > err) err = r;
+            if (r > err) err = r;                 /* NaN terms drop out, like v_max_f64 */
         }
+        if (!(err < 1.0e300) || !state_finite(yn)) bad = 1;
         ++attempts;
-        int forced = (attempts >= max_steps) || (hh <= 1e-9 * T);
-        if (attempts >= max_steps) st->capped = 1;
+        if (last_chance) st->capped = 1;
+        if (bad && (last_chance || hh <= 1.0e-9 * T)) {
+            for (int i = 0; i < NY; ++i) y[i] = NAN;
+            st->poisoned = 1;
+            break;
+        } else if (!bad && (err <= 1.0 || last_chance)) {
+            memcpy(y, yn, sizeof(yn));
+            t = (hh == rem) ? T : t + hh;
+            st->steps++;
+        } else {
+            st->rejected++;
+        }
         double fac;
         if (bad) fac = 0.2;
         else if (err == 0.0) fac = 5.0;
         else { fac = 0.9 * pow(err, -0.2); if (fac < 0.2) fac = 0.2; if (fac > 5.0) fac = 5.0; }
-        if ((!bad && err <= 1.0) || forced) {
-            memcpy(y, yn, sizeof(yn));
-            t += hh; if (hh == rem) t = T;
-            st->steps++;
-            if (tb->fsal) { memcpy(k[0], k[tb->stages - 1], sizeof(k[0])); have_k1 = 1; }
-            else have_k1 = 0;
-        } else {
-            st->rejected++;
-            have_k1 = 1;
-        }
         h = hh * fac;
     }
     *h_carry = h;
@@ -388,8 +379,14 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
 
             /* model.py:640 -- the one place that is not a restatement (see header) */
             if (n_integ == SIMPLYP_INTEG_RK4) rk4_day(y, &op, o->step_len, o->substeps, st);
-            else embedded_day(n_integ == 2 ? &DOPRI5 : &CASH_KARP, y, &op, o->step_len, o->rtol, o->atol,
-                              o->max_steps, &h_carry, st);
+            else cashkarp_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
+            if (o->project_vr) {
+                /* Drift control (not in the reference).  The reference's own equations (:127-131) imply
+                 * dVr = dQr * (1-b_Q) L / (a_Q 86400 Qr^b_Q), and Vr0 (:457-459) starts on that curve, so
+                 * Vr == L Qr^(1-b_Q) / (a_Q 86400) for all t; Vr has no restoring term and a one-step
+                 * integrator random-walks off it.  Re-impose it once per day. */
+                y[3] = L_reach * pow(y[4], 1.0 - b_Q) / (a_Q * 8.64 * 10000);
+            }
             const double* res = y;                                                               /* :643 */
             for (int i = 0; i < NY; ++i) if (!isfinite(res[i])) stat |= SIMPLYP_STATUS_NONFINITE;
 
@@ -440,12 +437,13 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
         }
     }
     if (st->capped) stat |= SIMPLYP_STATUS_STEPCAP;
+    if (st->poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
     status[e] = stat;
     free(route);
 }
 
 /* Same arguments as simplyp_run() minus the context; every pointer is a host pointer.
- * opts->integrator: 0 RK4, 1 Cash-Karp, 2 Dormand-Prince (oracle-only experiment). */
+ * n_threads > 1 runs members in parallel with OpenMP (cpu_baseline 'all cores' leg). */
 int simplyp_oracle_run(const simplyp_dims* dims, const simplyp_opts* opts,
                        const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
                        const double* member_params, const double* reach_params,
@@ -469,7 +467,7 @@ int simplyp_oracle_run(const simplyp_dims* dims, const simplyp_opts* opts,
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : rhs, steps, rej)
 #endif
     for (int e = 0; e < dims->E; ++e) {
-        integ_stats st = {0, 0, 0, 0};
+        integ_stats st = {0, 0, 0, 0, 0};
         run_member(e, dims, opts, forcing, doy, forcing_of_member, member_params, reach_params, up_ptr, up_idx,
                    out_slot, n_out_reaches, opts->integrator, out, member_status, &st);
         rhs += st.rhs; steps += st.steps; rej += st.rejected;

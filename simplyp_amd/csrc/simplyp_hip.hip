@@ -1,0 +1,463 @@
+// simplyp_hip.hip -- C ABI (include/simplyp.h) over the gfx950 kernels: context, routing
+// schedule, launches.  Built by __graft_entry__.build() into simplyp_amd/csrc/libsimplyp_hip.so.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "simplyp_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct simplyp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    DeviceBuf route;          // [n_slots][4][D][E] fp64
+    DeviceBuf sched;          // int32 schedule arrays
+    DeviceBuf counters;       // 3 x uint64
+    int n_launches = 0;
+    bool pending = false;
+    std::string error;
+};
+
+namespace {
+
+int fail(simplyp_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t err__ = (call);                                                                 \
+        if (err__ != hipSuccess)                                                                   \
+            return fail(ctx, SIMPLYP_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(err__)); \
+    } while (0)
+
+int ensure(simplyp_ctx* ctx, DeviceBuf& b, size_t bytes)
+{
+    if (bytes <= b.bytes) return SIMPLYP_OK;
+    if (b.ptr) { (void)hipFree(b.ptr); b.ptr = nullptr; b.bytes = 0; }
+    hipError_t err = hipMalloc(&b.ptr, bytes);
+    if (err != hipSuccess)
+        return fail(ctx, SIMPLYP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(err));
+    b.bytes = bytes;
+    return SIMPLYP_OK;
+}
+
+// One launch = a set of mutually independent chains; a chain = reaches one thread walks in order.
+struct Launch {
+    std::vector<int> chain_ptr;     // n_chains + 1, offsets into chain_reach
+    std::vector<int> chain_reach;
+};
+
+struct Schedule {
+    std::vector<Launch> launches;
+    std::vector<int> route_slot;    // [S], -1 when nobody reads the reach's series
+    int n_slots = 0;
+};
+
+// Routing schedule from the upstream CSR (reference: SC loop in ascending id, model.py:365, each
+// reach reading its upstream reaches' finished series, :521-528).  Reaches whose upstream reaches
+// are all done form a launch; a reach's single downstream reach is appended to the same chain
+// (processed by the same thread, "sequential chain inside the kernel") when nothing else feeds it
+// that is not already done.  Series slots are recycled as soon as every reader has finished;
+// inside a chain the slots alternate, since element k+1 is the only reader of element k.
+int build_schedule(simplyp_ctx* ctx, int S, const int32_t* up_ptr, const int32_t* up_idx, Schedule& sch)
+{
+    std::vector<std::vector<int>> down(S);
+    for (int s = 0; s < S; ++s) {
+        if (up_ptr[s + 1] < up_ptr[s]) return fail(ctx, SIMPLYP_ERR_TOPOLOGY, "up_ptr not monotone at reach %d", s);
+        for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) {
+            const int u = up_idx[k];
+            if (u < 0 || u >= s)
+                return fail(ctx, SIMPLYP_ERR_TOPOLOGY, "reach %d lists upstream reach %d (must be in [0, %d))", s, u, s);
+            down[u].push_back(s);
+        }
+    }
+    sch.route_slot.assign(S, -1);
+    std::vector<char> done(S, 0), taken(S, 0);
+    std::vector<int> readers_left(S, 0);
+    for (int s = 0; s < S; ++s) readers_left[s] = (int)down[s].size();
+    std::vector<int> free_slots;
+    int n_done = 0;
+    auto alloc_slot = [&]() {
+        if (!free_slots.empty()) { int v = free_slots.back(); free_slots.pop_back(); return v; }
+        return sch.n_slots++;
+    };
+    while (n_done < S) {
+        Launch L;
+        L.chain_ptr.push_back(0);
+        for (int s = 0; s < S; ++s) {
+            if (done[s] || taken[s]) continue;
+            bool ready = true;
+            for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) ready = ready && done[up_idx[k]];
+            if (!ready) continue;
+            int cur = s;
+            taken[cur] = 1;
+            L.chain_reach.push_back(cur);
+            for (;;) {
+                if (down[cur].size() != 1) break;
+                const int dn = down[cur][0];
+                if (taken[dn] || done[dn]) break;
+                bool ok = true;
+                for (int k = up_ptr[dn]; k < up_ptr[dn + 1]; ++k)
+                    ok = ok && (up_idx[k] == cur || done[up_idx[k]]);
+                if (!ok) break;
+                taken[dn] = 1;
+                L.chain_reach.push_back(dn);
+                cur = dn;
+            }
+            L.chain_ptr.push_back((int)L.chain_reach.size());
+        }
+        if (L.chain_reach.empty()) return fail(ctx, SIMPLYP_ERR_TOPOLOGY, "reach graph has no schedulable reach");
+        // Series slots.  A slot is column-partitioned by member, and a chain is walked by one thread per
+        // member, so a slot released inside a chain (its only reader was the next element) may be reused
+        // by later elements of the SAME chain at once; every other release waits for the launch to end.
+        std::vector<int> pending;
+        for (size_t c = 0; c + 1 < L.chain_ptr.size(); ++c) {
+            std::vector<int> local_free;
+            int prev = -1;
+            for (int i = L.chain_ptr[c]; i < L.chain_ptr[c + 1]; ++i) {
+                const int s = L.chain_reach[i];
+                if (!down[s].empty()) {
+                    if (!local_free.empty()) { sch.route_slot[s] = local_free.back(); local_free.pop_back(); }
+                    else sch.route_slot[s] = alloc_slot();
+                }
+                for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) {
+                    const int u = up_idx[k];
+                    if (--readers_left[u] == 0 && sch.route_slot[u] >= 0)
+                        (u == prev ? local_free : pending).push_back(sch.route_slot[u]);
+                }
+                prev = s;
+            }
+            pending.insert(pending.end(), local_free.begin(), local_free.end());
+        }
+        free_slots.insert(free_slots.end(), pending.begin(), pending.end());
+        for (int s : L.chain_reach) { done[s] = 1; ++n_done; }
+        sch.launches.push_back(std::move(L));
+    }
+    return SIMPLYP_OK;
+}
+
+int popcount32(uint32_t v) { return __builtin_popcount(v); }
+
+int check_args(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts, const void* forcing,
+               const void* mp, const void* rp, const int32_t* up_ptr, const void* out, const void* status,
+               const int32_t* out_reaches, int32_t n_out_reaches)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (!dims || !opts) return fail(ctx, SIMPLYP_ERR_ARG, "dims/opts is NULL");
+    if (dims->E <= 0 || dims->S <= 0 || dims->D <= 0 || dims->n_forcing_sets <= 0)
+        return fail(ctx, SIMPLYP_ERR_ARG, "bad dims E=%d S=%d D=%d n_forcing_sets=%d", dims->E, dims->S, dims->D,
+                    dims->n_forcing_sets);
+    if (!forcing || !mp || !rp || !up_ptr || !out || !status)
+        return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
+    if (opts->integrator != SIMPLYP_INTEG_RK4 && opts->integrator != SIMPLYP_INTEG_CASHKARP)
+        return fail(ctx, SIMPLYP_ERR_ARG, "unknown integrator %d", opts->integrator);
+    if (opts->integrator == SIMPLYP_INTEG_RK4 && opts->substeps <= 0)
+        return fail(ctx, SIMPLYP_ERR_ARG, "RK4 needs substeps >= 1 (got %d)", opts->substeps);
+    if (opts->integrator == SIMPLYP_INTEG_CASHKARP && (!(opts->rtol > 0.0) || !(opts->atol >= 0.0) || opts->max_steps < 1))
+        return fail(ctx, SIMPLYP_ERR_ARG, "Cash-Karp needs rtol > 0, atol >= 0, max_steps >= 1");
+    if (!(opts->step_len > 0.0)) return fail(ctx, SIMPLYP_ERR_ARG, "step_len must be > 0");
+    if (opts->sc_qr0 < 0 || opts->sc_qr0 >= dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "sc_qr0 out of range");
+    if ((opts->out_mask & SIMPLYP_MASK_ALL) == 0u || (opts->out_mask & ~SIMPLYP_MASK_ALL) != 0u)
+        return fail(ctx, SIMPLYP_ERR_ARG, "out_mask must select 1..%d of the columns", (int)SIMPLYP_N_OUT);
+    if (out_reaches) {
+        if (n_out_reaches <= 0 || n_out_reaches > dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "bad n_out_reaches");
+        for (int k = 0; k < n_out_reaches; ++k)
+            if (out_reaches[k] < 0 || out_reaches[k] >= dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "out_reaches[%d] out of range", k);
+    }
+    return SIMPLYP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int simplyp_abi_version(void) { return SIMPLYP_ABI_VERSION; }
+
+int simplyp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int simplyp_ctx_create(int device, simplyp_ctx** out)
+{
+    if (!out) return fail(nullptr, SIMPLYP_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int n = simplyp_device_count();
+    if (device < 0 || device >= n)
+        return fail(nullptr, SIMPLYP_ERR_DEVICE, "device %d not available (%d HIP device(s) visible)", device, n);
+    simplyp_ctx* ctx = new (std::nothrow) simplyp_ctx();
+    if (!ctx) return fail(nullptr, SIMPLYP_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) { ctx->own_stream = true; err = hipEventCreate(&ctx->ev_start); }
+    if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
+    if (err != hipSuccess) {
+        fail(nullptr, SIMPLYP_ERR_DEVICE, "context creation on device %d failed: %s", device, hipGetErrorString(err));
+        simplyp_ctx_destroy(ctx);
+        return SIMPLYP_ERR_DEVICE;
+    }
+    *out = ctx;
+    return SIMPLYP_OK;
+}
+
+int simplyp_ctx_set_stream(simplyp_ctx* ctx, void* stream)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is pending; call simplyp_sync first");
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr; ctx->own_stream = false; }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return SIMPLYP_OK;
+}
+
+void simplyp_ctx_destroy(simplyp_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->route.ptr) (void)hipFree(ctx->route.ptr);
+    if (ctx->sched.ptr) (void)hipFree(ctx->sched.ptr);
+    if (ctx->counters.ptr) (void)hipFree(ctx->counters.ptr);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* simplyp_last_error(const simplyp_ctx* ctx)
+{
+    return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, int32_t n_out_reaches)
+{
+    if (!dims || !opts) return 0;
+    const int64_t nor = n_out_reaches > 0 ? n_out_reaches : dims->S;
+    return (int64_t)popcount32(opts->out_mask & SIMPLYP_MASK_ALL) * dims->D * nor * dims->E * (int64_t)sizeof(double);
+}
+
+int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_t* n_launches, int32_t* n_slots,
+                 int32_t* launch_of_reach, int32_t* chain_of_reach, int32_t* pos_in_chain, int32_t* route_slot)
+{
+    if (S <= 0 || !up_ptr || (up_ptr[S] > 0 && !up_idx)) return fail(nullptr, SIMPLYP_ERR_ARG, "bad plan arguments");
+    simplyp_ctx tmp;
+    Schedule sch;
+    int rc = build_schedule(&tmp, S, up_ptr, up_idx, sch);
+    if (rc != SIMPLYP_OK) { g_create_error = tmp.error; return rc; }
+    if (n_launches) *n_launches = (int32_t)sch.launches.size();
+    if (n_slots) *n_slots = sch.n_slots;
+    for (size_t l = 0; l < sch.launches.size(); ++l) {
+        const Launch& L = sch.launches[l];
+        for (size_t c = 0; c + 1 < L.chain_ptr.size(); ++c)
+            for (int i = L.chain_ptr[c]; i < L.chain_ptr[c + 1]; ++i) {
+                const int s = L.chain_reach[i];
+                if (launch_of_reach) launch_of_reach[s] = (int32_t)l;
+                if (chain_of_reach) chain_of_reach[s] = (int32_t)c;
+                if (pos_in_chain) pos_in_chain[s] = i - L.chain_ptr[c];
+            }
+    }
+    if (route_slot) for (int s = 0; s < S; ++s) route_slot[s] = sch.route_slot[s];
+    return SIMPLYP_OK;
+}
+
+int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
+                      const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                      const double* member_params, const double* reach_params,
+                      const int32_t* up_ptr, const int32_t* up_idx,
+                      const int32_t* out_reaches, int32_t n_out_reaches,
+                      double* out, int32_t* member_status)
+{
+    int rc = check_args(ctx, dims, opts, forcing, member_params, reach_params, up_ptr, out, member_status,
+                        out_reaches, n_out_reaches);
+    if (rc != SIMPLYP_OK) return rc;
+    if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is already pending on this context; call simplyp_sync");
+    if (opts->dynamic_erod && !doy) return fail(ctx, SIMPLYP_ERR_ARG, "doy is required when dynamic_erod is set");
+    const int E = dims->E, S = dims->S, D = dims->D;
+    if (up_ptr[S] > 0 && !up_idx) return fail(ctx, SIMPLYP_ERR_ARG, "up_idx is NULL but up_ptr lists upstream reaches");
+
+    Schedule sch;
+    rc = build_schedule(ctx, S, up_ptr, up_idx, sch);
+    if (rc != SIMPLYP_OK) return rc;
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- device scratch: routing series, schedule, counters ----
+    const size_t slot_bytes = (size_t)4 * D * E * sizeof(double);
+    if (sch.n_slots > 0) {
+        rc = ensure(ctx, ctx->route, slot_bytes * sch.n_slots);
+        if (rc != SIMPLYP_OK) return rc;
+    }
+    rc = ensure(ctx, ctx->counters, 3 * sizeof(unsigned long long));
+    if (rc != SIMPLYP_OK) return rc;
+
+    // int32 schedule block: up_ptr | up_idx | route_slot | out_slot | per launch: chain_ptr | chain_reach
+    std::vector<int> out_slot(S, out_reaches ? -1 : 0);
+    if (out_reaches) for (int k = 0; k < n_out_reaches; ++k) out_slot[out_reaches[k]] = k;
+    else { for (int s = 0; s < S; ++s) out_slot[s] = s; n_out_reaches = S; }
+    std::vector<int> host;
+    const size_t off_up_ptr = host.size(); host.insert(host.end(), up_ptr, up_ptr + S + 1);
+    const size_t off_up_idx = host.size(); if (up_ptr[S] > 0) host.insert(host.end(), up_idx, up_idx + up_ptr[S]);
+    const size_t off_rslot = host.size(); host.insert(host.end(), sch.route_slot.begin(), sch.route_slot.end());
+    const size_t off_oslot = host.size(); host.insert(host.end(), out_slot.begin(), out_slot.end());
+    std::vector<size_t> off_cptr, off_creach;
+    for (const Launch& L : sch.launches) {
+        off_cptr.push_back(host.size()); host.insert(host.end(), L.chain_ptr.begin(), L.chain_ptr.end());
+        off_creach.push_back(host.size()); host.insert(host.end(), L.chain_reach.begin(), L.chain_reach.end());
+    }
+    rc = ensure(ctx, ctx->sched, host.size() * sizeof(int));
+    if (rc != SIMPLYP_OK) return rc;
+    // pageable source: the copy is staged before hipMemcpyAsync returns, `host` may go out of scope
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sched.ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(member_status, 0, (size_t)E * sizeof(int32_t), ctx->stream));
+
+    const int* dsched = (const int*)ctx->sched.ptr;
+    simplyp::KernelArgs a;
+    a.E = E; a.S = S; a.D = D; a.n_sets = dims->n_forcing_sets;
+    a.forcing = forcing; a.doy = doy; a.forcing_of_member = forcing_of_member;
+    a.mp = member_params; a.rp = reach_params;
+    a.out = out; a.status = member_status;
+    a.counters = (unsigned long long*)ctx->counters.ptr;
+    a.route = (double*)ctx->route.ptr;
+    a.up_ptr = dsched + off_up_ptr; a.up_idx = dsched + off_up_idx;
+    a.route_slot = dsched + off_rslot; a.out_slot = dsched + off_oslot;
+    a.n_out_reaches = n_out_reaches;
+    a.out_mask = opts->out_mask & SIMPLYP_MASK_ALL;
+    a.integrator = opts->integrator; a.substeps = opts->substeps; a.max_steps = opts->max_steps;
+    a.dynamic_epc0 = opts->dynamic_epc0; a.dynamic_erod = opts->dynamic_erod;
+    a.run_mode_cal = opts->run_mode_cal; a.sc_qr0 = opts->sc_qr0; a.project_vr = opts->project_vr;
+    a.rtol = opts->rtol; a.atol = opts->atol; a.step_len = opts->step_len;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    const unsigned gx = (unsigned)((E + simplyp::WAVE - 1) / simplyp::WAVE);
+    for (size_t l = 0; l < sch.launches.size(); ++l) {
+        a.chain_ptr = dsched + off_cptr[l];
+        a.chain_reach = dsched + off_creach[l];
+        const unsigned n_chains = (unsigned)sch.launches[l].chain_ptr.size() - 1u;
+        dim3 grid(gx, n_chains, 1), block(simplyp::WAVE, 1, 1);
+        if (opts->integrator == SIMPLYP_INTEG_RK4)
+            hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_RK4>, grid, block, 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP>, grid, block, 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->n_launches = (int)sch.launches.size();
+    ctx->pending = true;
+    return SIMPLYP_OK;
+}
+
+int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (!ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "no run pending");
+    ctx->pending = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        unsigned long long c[3] = {0, 0, 0};
+        HIP_TRY(ctx, hipMemcpy(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+        memset(stats, 0, sizeof(*stats));
+        stats->rhs_evals = c[0]; stats->steps = c[1]; stats->rejected = c[2];
+        stats->kernel_ms = ms;
+        stats->n_launches = ctx->n_launches;
+    }
+    return SIMPLYP_OK;
+}
+
+int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
+                const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                const double* member_params, const double* reach_params,
+                const int32_t* up_ptr, const int32_t* up_idx,
+                const int32_t* out_reaches, int32_t n_out_reaches,
+                double* out, int32_t* member_status, simplyp_stats* stats)
+{
+    int rc = simplyp_run_async(ctx, dims, opts, forcing, doy, forcing_of_member, member_params, reach_params,
+                               up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status);
+    if (rc != SIMPLYP_OK) return rc;
+    return simplyp_sync(ctx, stats);
+}
+
+void* simplyp_host_alloc(int64_t bytes)
+{
+    void* p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void simplyp_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+void* simplyp_device_alloc(simplyp_ctx* ctx, int64_t bytes)
+{
+    if (!ctx || bytes <= 0) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&p, (size_t)bytes) != hipSuccess) {
+        fail(ctx, SIMPLYP_ERR_NOMEM, "hipMalloc(%lld bytes) failed", (long long)bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void simplyp_device_free(simplyp_ctx* ctx, void* p)
+{
+    if (!ctx || !p) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipFree(p);
+}
+
+int simplyp_memcpy_h2d(simplyp_ctx* ctx, void* dst, const void* src, int64_t bytes)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SIMPLYP_OK;
+}
+
+int simplyp_memcpy_d2h(simplyp_ctx* ctx, void* dst, const void* src, int64_t bytes)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SIMPLYP_OK;
+}
+
+}  // extern "C"

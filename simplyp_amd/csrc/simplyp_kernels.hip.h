@@ -1,0 +1,638 @@
+// simplyp_kernels.hip.h -- device code of the SimplyP time-stepping engine for gfx950 (MI355X).
+//
+// One thread integrates one (ensemble member, reach) 12-variable system through the whole
+// daily series: the work of the reference's `for SC` x `for idx` loop nest around
+// `odeint(ode_f, ...)` (Current_Release/v0-2A/simplyP/model.py:365, :491, :640).
+//
+//   * thread -> member e = blockIdx.x*64 + lane, routing chain = blockIdx.y.  A chain is a
+//     list of reaches the same thread walks in order (reach-outer, day-inner, like the
+//     reference), reading the upstream reaches' daily series it or an earlier launch wrote.
+//   * one wavefront per workgroup: a member needs no cooperation, so 64-thread groups give
+//     the dispatcher the finest grain to spread waves over the 1024 SIMDs.
+//   * met forcing (P, PET, day-of-year) is staged per wavefront through LDS in tiles of
+//     TILE_D days; every lane reads the same LDS word (broadcast, conflict-free).
+//   * all per-member data is ensemble-major: lane e touches base[e], so every global load and
+//     store of a wave is one contiguous 512-byte segment.
+//   * the right-hand side is the reference's ode_f (model.py:58-187) with everything that is
+//     constant within a day hoisted into `DayConst`; Qr**b_Q and Qr**k_M share one log.
+//   * no MFMA: the system is 12 scalar fluxes, there is no contraction to put on matrix cores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/simplyp.h"
+
+namespace simplyp {
+
+constexpr int WAVE = 64;
+constexpr int TILE_D = 256;     // days of forcing staged in LDS at a time (256*(8+8+4) B = 5 KB)
+
+struct KernelArgs {
+    int E, S, D, n_sets;
+    const double* forcing;          // [n_sets][2][D]
+    const int* doy;                 // [D]
+    const int* forcing_of_member;   // [E] or nullptr
+    const double* mp;               // [NP_M][E]
+    const double* rp;               // [NP_R][S][E]
+    double* out;                    // [ncols][D][n_out_reaches][E]
+    int* status;                    // [E]
+    unsigned long long* counters;   // rhs, steps, rejected
+    double* route;                  // [n_slots][4][D][E] daily series handed downstream
+    const int* chain_ptr;           // [n_chains+1]   (this launch)
+    const int* chain_reach;         // reach ids in processing order
+    const int* up_ptr;              // [S+1]
+    const int* up_idx;              // CSR of directly-upstream reaches
+    const int* route_slot;          // [S] slot a reach writes its series to, or -1
+    const int* out_slot;            // [S] position among the output reaches, or -1
+    int n_out_reaches;
+    unsigned out_mask;
+    int integrator, substeps, max_steps;
+    int dynamic_epc0, dynamic_erod, run_mode_cal, sc_qr0, project_vr;
+    double rtol, atol, step_len;
+};
+
+// ---------------------------------------------------------------------------------------
+// fp64 elementary functions on the VALU, trimmed to what this kernel needs: finite,
+// in-range arguments (no inf/nan/denormal branches), ~1 ulp.
+
+// exp(x) for |x| < 700.  n = rint(x/ln2), r = x - n ln2 (two-word ln2), degree-13 Taylor on
+// |r| <= 0.3466 (remainder < 4e-18), scale by 2^n.
+__device__ __forceinline__ double sp_exp(double x)
+{
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                    // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);        // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);       // 1/11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);       // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);      // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);        // 1/8!
+    p = __builtin_fma(p, r, 1.984126984126984e-04);       // 1/7!
+    p = __builtin_fma(p, r, 1.388888888888889e-03);       // 1/6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);       // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);      // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);      // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+// 1/x: hardware seed + two Newton steps (full double precision for normal x).
+__device__ __forceinline__ double sp_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// log(x) for normal x > 0.  x = 2^k (1+f), sqrt(1/2) < 1+f <= sqrt(2); s = f/(2+f);
+// log(1+f) = f - hfsq + s (hfsq + R(s^2)), R = the classic degree-7 even minimax polynomial
+// (fdlibm e_log.c coefficients Lg1..Lg7).
+__device__ __forceinline__ double sp_log(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = f * sp_rcp(2.0 + f);
+    const double z = s * s;
+    double R = 1.479819860511658591e-01;
+    R = __builtin_fma(R, z, 1.531383769920937332e-01);
+    R = __builtin_fma(R, z, 1.818357216161805012e-01);
+    R = __builtin_fma(R, z, 2.222219843214978396e-01);
+    R = __builtin_fma(R, z, 2.857142874366239149e-01);
+    R = __builtin_fma(R, z, 3.999999999940941908e-01);
+    R = __builtin_fma(R, z, 6.666666666666735130e-01);
+    R = R * z;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    // k ln2_hi + (f - (hfsq - (s (hfsq + R) + k ln2_lo)))
+    const double t = __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10);
+    return __builtin_fma(dk, 6.93147180369123816490e-01, f - (hfsq - t));
+}
+
+// ---------------------------------------------------------------------------------------
+// Right-hand side.  State y[8] = VsA, VsS, Vg, Vr, Qr, Msus, TDPr, PPr (the reference's slots
+// 0,1,2,3,4,6,8,10); the four daily integrators (slots 5,7,9,11) never feed back, so only their
+// integrands q[4] = Qr, Msus Qr/Vr, TDPr Qr/Vr, PPr Qr/Vr are returned.
+
+struct DayConst {
+    // soil boxes (model.py:105-110)
+    double c0;          // P (1 - f_quick)
+    double aE;          // alpha * PET
+    double mu, fc, inv_d;       // inv_d = 1 / (0.01 fc)
+    double invTsA, invTsS;
+    // groundwater (:121-124)
+    double invTg, Qgmin, inv_dg, beta, fA, fS;
+    // reach hydrology (:127-132)
+    double qin;         // Qq + Qr_US
+    double omb;         // 1 - beta
+    double cQ;          // a_Q 86400 / ((1 - b_Q) L_reach)
+    double bQ, kM;
+    // sediment (:138-147)
+    double Esum;        // f_Ar Esus_A + f_IG Esus_IG + f_S Esus_S
+    double MsusUS;
+    // TDP (:154-168)
+    double tA, tS;      // coefficients of QsA, QsS
+    double tg;          // TDPg * A_catch
+    double tconst;      // quick-flow terms + TDPeff + TDPr_US
+    // PP (:171-180)
+    double cPP, PPrUS;
+};
+
+// f_x(x, threshold, 0.01) with u = x - threshold and inv_d = 1/(0.01 threshold) (model.py:23-37):
+// 0 below the threshold, 1 above threshold + d, 3s^2 - 2s^3 in between -- as one clamped cubic.
+__device__ __forceinline__ double gate(double u, double inv_d)
+{
+    double s = u * inv_d;
+    s = __builtin_fmin(__builtin_fmax(s, 0.0), 1.0);
+    return s * s * __builtin_fma(-2.0, s, 3.0);
+}
+
+__device__ __forceinline__ void rhs(const double (&y)[8], const DayConst& c, double (&dy)[8], double (&q)[4])
+{
+    const double uA = y[0] - c.fc, uS = y[1] - c.fc;
+    const double QsA = uA * gate(uA, c.inv_d) * c.invTsA;                         // :105
+    const double QsS = uS * gate(uS, c.inv_d) * c.invTsS;                         // :109
+    const double eA = sp_exp(-c.mu * y[0]), eS = sp_exp(-c.mu * y[1]);
+    dy[0] = __builtin_fma(c.aE, eA - 1.0, c.c0) - QsA;                            // :106
+    dy[1] = __builtin_fma(c.aE, eS - 1.0, c.c0) - QsS;                            // :110
+    const double Qsum = __builtin_fma(c.fA, QsA, c.fS * QsS);
+    const double ug = __builtin_fma(y[2], c.invTg, -c.Qgmin);
+    const double Qg = __builtin_fma(gate(ug, c.inv_dg), ug, c.Qgmin);             // :121-122
+    dy[2] = __builtin_fma(c.beta, Qsum, -Qg);                                     // :124
+    const double Qr = y[4];
+    const double inflow = __builtin_fma(c.omb, Qsum, c.qin) + Qg - Qr;            // :127-129
+    const double lq = sp_log(Qr);
+    const double pb = sp_exp(c.bQ * lq), pk = sp_exp(c.kM * lq);                  // Qr**b_Q, Qr**k_M
+    dy[4] = inflow * c.cQ * pb;                                                   // :130
+    dy[3] = inflow;                                                               // :131
+    const double qv = Qr * sp_rcp(y[3]);
+    const double oM = y[5] * qv, oT = y[6] * qv, oP = y[7] * qv;
+    dy[5] = __builtin_fma(c.Esum, pk, c.MsusUS) - oM;                             // :141-145
+    dy[6] = __builtin_fma(c.tA, QsA, __builtin_fma(c.tS, QsS, __builtin_fma(c.tg, Qg, c.tconst))) - oT;   // :154-166
+    dy[7] = __builtin_fma(c.cPP, pk, c.PPrUS) - oP;                               // :171-178
+    q[0] = Qr; q[1] = oM; q[2] = oT; q[3] = oP;                                   // :132,:147,:168,:180
+}
+
+// ---------------------------------------------------------------------------------------
+// Integrators over one day [0, T].  yq[4] (the daily integrators) starts at 0 (model.py:618).
+
+__device__ __forceinline__ void rk4_day(double (&y)[8], double (&yq)[4], const DayConst& c, double T, int n)
+{
+    const double h = T / (double)n;
+    for (int st = 0; st < n; ++st) {
+        double k[8], kq[4], yt[8], acc[8], accq[4];
+        rhs(y, c, k, kq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i] = k[i]; yt[i] = __builtin_fma(0.5 * h, k[i], y[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accq[i] = kq[i];
+        rhs(yt, c, k, kq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i] = __builtin_fma(2.0, k[i], acc[i]); yt[i] = __builtin_fma(0.5 * h, k[i], y[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accq[i] = __builtin_fma(2.0, kq[i], accq[i]);
+        rhs(yt, c, k, kq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i] = __builtin_fma(2.0, k[i], acc[i]); yt[i] = __builtin_fma(h, k[i], y[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accq[i] = __builtin_fma(2.0, kq[i], accq[i]);
+        rhs(yt, c, k, kq);
+        const double h6 = h * (1.0 / 6.0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = __builtin_fma(h6, acc[i] + k[i], y[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma(h6, accq[i] + kq[i], yq[i]);
+    }
+}
+
+// Cash-Karp 5(4), per-lane step control; the rule is documented (and mirrored for the parity
+// tests) in oracle/simplyp_oracle.c `embedded_day`.  Lanes that have reached T idle with a zero
+// step until the slowest lane of the wavefront is done.
+struct CkCounters { unsigned rhs, steps, rejected; bool capped, poisoned; };
+
+__device__ __forceinline__ void ck_day(double (&y)[8], double (&yq)[4], const DayConst& c, double T,
+                                       double rtol, double atol, int max_steps, double& h_carry, CkCounters& cnt)
+{
+    constexpr double a21 = 1.0 / 5;
+    constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
+    constexpr double a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
+    constexpr double a51 = -11.0 / 54, a52 = 5.0 / 2, a53 = -70.0 / 27, a54 = 35.0 / 27;
+    constexpr double a61 = 1631.0 / 55296, a62 = 175.0 / 512, a63 = 575.0 / 13824, a64 = 44275.0 / 110592, a65 = 253.0 / 4096;
+    constexpr double b1 = 37.0 / 378, b3 = 250.0 / 621, b4 = 125.0 / 594, b6 = 512.0 / 1771;
+    constexpr double e1 = 37.0 / 378 - 2825.0 / 27648, e3 = 250.0 / 621 - 18575.0 / 48384,
+                     e4 = 125.0 / 594 - 13525.0 / 55296, e5 = -277.0 / 14336, e6 = 512.0 / 1771 - 1.0 / 4;
+
+    double t = 0.0, h = h_carry;
+    if (!(h > 0.0) || h > T) h = T;
+    int attempts = 0;
+    bool alive = true;
+    // a member whose state is already non-finite is not integrated further
+#pragma unroll
+    for (int i = 0; i < 8; ++i) alive = alive && (__builtin_fabs(y[i]) < 1.0e300);
+    if (!alive) {
+        cnt.poisoned = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yq[i] = __builtin_nan("");
+    }
+
+    while (__any(alive)) {
+        const double rem = T - t;
+        double hh = h;
+        if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
+        const bool last_chance = (attempts + 1 >= max_steps);
+        if (last_chance) hh = rem;
+        if (!alive) hh = 0.0;
+
+        double k1[8], k2[8], k3[8], k4[8], k5[8], k6[8], kq[4], yt[8];
+        double sq[4], eq[4];                          // sum b_s kq_s, sum e_s kq_s
+        rhs(y, c, k1, kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sq[i] = b1 * kq[i]; eq[i] = e1 * kq[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yt[i] = __builtin_fma(hh, a21 * k1[i], y[i]);
+        rhs(yt, c, k2, kq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yt[i] = __builtin_fma(hh, __builtin_fma(a31, k1[i], a32 * k2[i]), y[i]);
+        rhs(yt, c, k3, kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b3, kq[i], sq[i]); eq[i] = __builtin_fma(e3, kq[i], eq[i]); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            yt[i] = __builtin_fma(hh, __builtin_fma(a41, k1[i], __builtin_fma(a42, k2[i], a43 * k3[i])), y[i]);
+        rhs(yt, c, k4, kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b4, kq[i], sq[i]); eq[i] = __builtin_fma(e4, kq[i], eq[i]); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            yt[i] = __builtin_fma(hh, __builtin_fma(a51, k1[i], __builtin_fma(a52, k2[i], __builtin_fma(a53, k3[i], a54 * k4[i]))), y[i]);
+        rhs(yt, c, k5, kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) eq[i] = __builtin_fma(e5, kq[i], eq[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            yt[i] = __builtin_fma(hh, __builtin_fma(a61, k1[i], __builtin_fma(a62, k2[i], __builtin_fma(a63, k3[i],
+                                  __builtin_fma(a64, k4[i], a65 * k5[i])))), y[i]);
+        rhs(yt, c, k6, kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b6, kq[i], sq[i]); eq[i] = __builtin_fma(e6, kq[i], eq[i]); }
+
+        double err = 0.0;
+        double yn[8], yqn[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double inc = __builtin_fma(b1, k1[i], __builtin_fma(b3, k3[i], __builtin_fma(b4, k4[i], b6 * k6[i])));
+            const double ee = __builtin_fma(e1, k1[i], __builtin_fma(e3, k3[i], __builtin_fma(e4, k4[i],
+                              __builtin_fma(e5, k5[i], e6 * k6[i]))));
+            yn[i] = __builtin_fma(hh, inc, y[i]);
+            const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(y[i]), __builtin_fabs(yn[i])), atol);
+            err = __builtin_fmax(err, __builtin_fabs(hh * ee) * __builtin_amdgcn_rcp(sc));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            yqn[i] = __builtin_fma(hh, sq[i], yq[i]);
+            const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(yq[i]), __builtin_fabs(yqn[i])), atol);
+            err = __builtin_fmax(err, __builtin_fabs(hh * eq[i]) * __builtin_amdgcn_rcp(sc));
+        }
+        // v_max_f64 drops NaNs, so test the new state itself
+        bool bad = !(err < 1.0e300);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bad = bad || !(__builtin_fabs(yn[i]) < 1.0e300);
+
+        if (alive) {
+            ++attempts;
+            cnt.rhs += 6;
+            if (last_chance) cnt.capped = true;
+            const bool give_up = bad && (last_chance || hh <= 1.0e-9 * T);
+            if (give_up) {
+                // cannot be integrated: poison the state, flag the member, stop
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = __builtin_nan("");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yq[i] = __builtin_nan("");
+                cnt.poisoned = true;
+                alive = false;
+            } else if (!bad && (err <= 1.0 || last_chance)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = yn[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yq[i] = yqn[i];
+                t = (hh == rem) ? T : t + hh;
+                ++cnt.steps;
+                alive = t < T;
+            } else {
+                ++cnt.rejected;
+            }
+            float fac;
+            if (bad) fac = 0.2f;
+            else if (err == 0.0) fac = 5.0f;
+            else {
+                // 0.9 err^(-1/5) in fp32 (v_log_f32 / v_exp_f32): a step-size factor needs no more
+                fac = 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f((float)err));
+                fac = fminf(fmaxf(fac, 0.2f), 5.0f);
+            }
+            h = hh * (double)fac;
+        }
+    }
+    h_carry = h;
+}
+
+// ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int nc_type_of(double f_NC_A, double f_NC_S)     // model.py:325-334
+{
+    return f_NC_A > 0.0 ? 1 : (f_NC_S > 0.0 ? 2 : 0);
+}
+
+// discretized_soilP (model.py:39-56) followed by the >= 0 clamps (:696-699)
+__device__ __forceinline__ void soil_p_update(double P_netInput, double A_catch, double KfMsoil, double EPC0,
+                                              double Qs, double Qq, double Vs, double& TDPs, double& Plab)
+{
+    const double a = P_netInput * A_catch * 100.0 / 365. + KfMsoil * EPC0;        // :42
+    const double b = (KfMsoil + Qs + Qq) / Vs;                                    // :43
+    const double aob = a / b;
+    const double emb = sp_exp(__builtin_fmax(-b, -700.0));
+    double T = aob + (TDPs - aob) * emb;                                          // :44
+    double sorp = 0.0;
+    if (Vs > 0.0)                                                                 // :50
+        sorp = KfMsoil * (a / (b * Vs) - EPC0 + (1.0 / b) * (T / Vs - a / (b * Vs)) * (1.0 - emb));   // :51
+    double Pl = Plab + sorp;                                                      // :54
+    TDPs = (0.0 > T) ? 0.0 : T;                                                   // :696 (NaN stays NaN, like Python max)
+    Plab = (0.0 > Pl) ? 0.0 : Pl;                                                 // :697
+}
+
+template <int INTEG>
+__global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
+{
+    __shared__ double s_P[TILE_D];
+    __shared__ double s_E[TILE_D];
+    __shared__ int s_doy[TILE_D];
+
+    const int lane = threadIdx.x;
+    const int e_raw = blockIdx.x * WAVE + lane;
+    const bool active = e_raw < a.E;
+    const int e = active ? e_raw : a.E - 1;           // inactive lanes shadow the last member, store nothing
+    const size_t E = (size_t)a.E;
+    const int S = a.S, D = a.D;
+
+#define MPv(idx) (a.mp[(size_t)(idx) * E + e])
+#define RPv(idx, s) (a.rp[((size_t)(idx) * S + (s)) * E + e])
+
+    const int set = a.forcing_of_member ? a.forcing_of_member[e] : 0;
+    const bool shared_forcing = (a.forcing_of_member == nullptr);
+    const double* Pser = a.forcing + (size_t)set * 2 * D;
+    const double* Eser = Pser + D;
+
+    // ---- member constants (model.py:349-361, 377-390) ----
+    const double fc = MPv(SIMPLYP_PM_FC), f_quick = MPv(SIMPLYP_PM_F_QUICK), alpha = MPv(SIMPLYP_PM_ALPHA);
+    const double beta = MPv(SIMPLYP_PM_BETA), T_g = MPv(SIMPLYP_PM_T_G), Qg_min = MPv(SIMPLYP_PM_QG_MIN);
+    const double a_Q = MPv(SIMPLYP_PM_A_Q), b_Q = MPv(SIMPLYP_PM_B_Q), k_M = MPv(SIMPLYP_PM_K_M);
+    const double T_s_A = MPv(SIMPLYP_PM_T_S_A), T_s_S = MPv(SIMPLYP_PM_T_S_S);
+    const double mu = -log(0.01) / fc;                                                            // :349
+    const double Qr_init = MPv(SIMPLYP_PM_QR0_INIT) * 86400 / (1000 * RPv(SIMPLYP_PR_A_CATCH, a.sc_qr0));   // :386
+
+    // NC type of the last sub-catchment: the reference's leaked loop variable (:330-334 -> :442,:676)
+    const int nc_leak = nc_type_of(RPv(SIMPLYP_PR_F_AR, S - 1) * RPv(SIMPLYP_PR_F_NC_AR, S - 1)
+                                   + RPv(SIMPLYP_PR_F_NC_IG, S - 1) * RPv(SIMPLYP_PR_F_IG, S - 1),
+                                   RPv(SIMPLYP_PR_F_NC_S, S - 1));
+
+    unsigned n_rhs = 0, n_steps = 0, n_rej = 0;
+    int stat = 0;
+
+    const int chain = blockIdx.y;
+    for (int ci = a.chain_ptr[chain]; ci < a.chain_ptr[chain + 1]; ++ci) {
+        const int s = a.chain_reach[ci];
+
+        // ---- per-reach constants and initial conditions (model.py:377-463) ----
+        const double A_catch = RPv(SIMPLYP_PR_A_CATCH, s);
+        const double f_Ar = RPv(SIMPLYP_PR_F_AR, s), f_IG = RPv(SIMPLYP_PR_F_IG, s), f_S = RPv(SIMPLYP_PR_F_S, s);
+        const double f_NC_Ar = RPv(SIMPLYP_PR_F_NC_AR, s), f_NC_IG = RPv(SIMPLYP_PR_F_NC_IG, s);
+        const double f_NC_S = RPv(SIMPLYP_PR_F_NC_S, s);
+        const double f_A = f_IG + f_Ar;                                                           // :318
+        const double f_NC_A = (f_Ar * f_NC_Ar) + (f_NC_IG * f_IG);                                // :319
+        const int nc_type = nc_type_of(f_NC_A, f_NC_S);
+        const double L_reach = RPv(SIMPLYP_PR_L_REACH, s);
+        const double Msoil = MPv(SIMPLYP_PM_MSOIL_M2) * 1000000 * A_catch;                        // :404
+        const double P_inactive = 1e-6 * MPv(SIMPLYP_PM_SOILPCONC_S) * Msoil;                     // :407
+        const double EPC0_0_A = MPv(SIMPLYP_PM_EPC0_INIT_A) * A_catch;                            // :412
+        const double EPC0_0_S = MPv(SIMPLYP_PM_EPC0_INIT_S) * A_catch;
+        const double Kf = a.run_mode_cal
+            ? 1e-6 * (MPv(SIMPLYP_PM_SOILPCONC_A) - MPv(SIMPLYP_PM_SOILPCONC_S)) / EPC0_0_A       // :451
+            : MPv(SIMPLYP_PM_KF);                                                                 // :453
+        const double KfMsoil = Kf * Msoil;
+        double TDPeff = RPv(SIMPLYP_PR_TDPEFF, s);
+        if (TDPeff != TDPeff) TDPeff = 0.0;                                                       // :462-463
+        const double Kv = L_reach / (a_Q * 8.64 * 10000);     // Vr = Kv Qr^(1-b_Q)              // :457-459
+
+        double y[8];
+        y[0] = fc; y[1] = fc;                                                                     // :377-378
+        y[4] = Qr_init;
+        y[2] = (beta * Qr_init) * T_g;                                                            // :389-390
+        y[3] = L_reach / (a_Q * pow(Qr_init, b_Q) * 8.64 * 10000) * Qr_init;                      // :457-459
+        y[5] = 0.0; y[6] = 0.0; y[7] = 0.0;                                                       // :396
+        double Plab_A = 1e-6 * (MPv(SIMPLYP_PM_SOILPCONC_A) - MPv(SIMPLYP_PM_SOILPCONC_S)) * Msoil;   // :415,:426
+        double TDPs_A = EPC0_0_A * fc;                                                            // :420
+        double Plab_NC = (nc_type == 2) ? Plab_A : 0.0;                                           // :429-434
+        double TDPs_NC = (nc_type == 2) ? TDPs_A : 0.0;
+        double conc_A = TDPs_A / fc;                                                              // :438
+        double conc_NC = TDPs_NC / fc;                                                            // :446 (VsA0 == VsS0)
+        double h_carry = a.step_len / (double)(a.substeps > 0 ? a.substeps : 1);
+
+        // per-reach pieces of the day constants
+        DayConst c;
+        c.mu = mu; c.fc = fc; c.inv_d = 1.0 / (0.01 * fc);
+        c.invTsA = 1.0 / T_s_A; c.invTsS = 1.0 / T_s_S;
+        c.invTg = 1.0 / T_g; c.Qgmin = Qg_min;
+        c.inv_dg = (Qg_min * 0.01 > 0.0) ? 1.0 / (Qg_min * 0.01) : 1.0e300;   // threshold 0 -> plain step
+        c.beta = beta; c.fA = f_A; c.fS = f_S;
+        c.omb = 1.0 - beta;
+        c.cQ = a_Q * (8.64 * 10000) / ((1 - b_Q) * L_reach);
+        c.bQ = b_Q; c.kM = k_M;
+        c.tg = MPv(SIMPLYP_PM_TDPG) * A_catch;                                                    // :163
+
+        const double slopeA = RPv(SIMPLYP_PR_S_AR, s), slopeIG = RPv(SIMPLYP_PR_S_IG, s), slopeS = RPv(SIMPLYP_PR_S_SN, s);
+        const double ES = MPv(SIMPLYP_PM_E_M) * RPv(SIMPLYP_PR_S_REACH, s);
+        const double C_cover_A0 = MPv(SIMPLYP_PM_C_COVER_A);
+        const double Esus_S = ES * slopeS * MPv(SIMPLYP_PM_C_COVER_S) * (1 - MPv(SIMPLYP_PM_C_MEAS_S));      // :591-594
+        const double Esus_IG = ES * slopeIG * MPv(SIMPLYP_PM_C_COVER_IG) * (1 - MPv(SIMPLYP_PM_C_MEAS_IG));
+        const double EA_fac = ES * slopeA * (1 - MPv(SIMPLYP_PM_C_MEAS_A));
+        const double f_spr = RPv(SIMPLYP_PR_F_SPR, s);
+        const double dmid0 = MPv(SIMPLYP_PM_D_MAXE_SPR), dmid1 = MPv(SIMPLYP_PM_D_MAXE_AUT);
+        const double C_out = C_cover_A0 - (60.0 * (1 - C_cover_A0) / (2 * (365 - 60.0)));         // :575-576
+        const double E_PP = MPv(SIMPLYP_PM_E_PP);
+        const double PnetA = MPv(SIMPLYP_PM_P_NETINPUT_A), PnetNC = MPv(SIMPLYP_PM_P_NETINPUT_NC);
+        const double wA = f_A * (1 - f_NC_A);                 // TDP source weights (:155-161)
+        const double wNC = f_A * f_NC_A + f_S * f_NC_S;
+
+        const int up_lo = a.up_ptr[s], up_hi = a.up_ptr[s + 1];
+        const int rslot = a.route_slot[s];
+        const int oslot = a.out_slot[s];
+        double* route_w = rslot >= 0 ? a.route + (size_t)rslot * 4 * D * E : nullptr;
+
+        for (int d0 = 0; d0 < D; d0 += TILE_D) {
+            const int nd = min(TILE_D, D - d0);
+            if (shared_forcing) {
+                __syncthreads();
+                for (int i = lane; i < nd; i += WAVE) { s_P[i] = Pser[d0 + i]; s_E[i] = Eser[d0 + i]; }
+                if (a.dynamic_erod) for (int i = lane; i < nd; i += WAVE) s_doy[i] = a.doy[d0 + i];
+                __syncthreads();
+            }
+            for (int dd = 0; dd < nd; ++dd) {
+                const int d = d0 + dd;
+                const double P = shared_forcing ? s_P[dd] : Pser[d];                              // :497
+                const double PET = shared_forcing ? s_E[dd] : Eser[d];                            // :498
+                const double Qq = f_quick * P;                                                    // :501
+
+                // upstream inputs (:508-544): same-day daily means / fluxes of the reaches above
+                double QrUS = 0.0, MsusUS = 0.0, TDPrUS = 0.0, PPrUS = 0.0;
+                for (int k = up_lo; k < up_hi; ++k) {
+                    const int u = a.up_idx[k];
+                    const double* r = a.route + (size_t)a.route_slot[u] * 4 * D * E + (size_t)d * E + e;
+                    QrUS += r[0] * (RPv(SIMPLYP_PR_A_CATCH, u) / A_catch);                        // :524-525
+                    MsusUS += r[(size_t)D * E];
+                    TDPrUS += r[(size_t)2 * D * E];
+                    PPrUS += r[(size_t)3 * D * E];                                                // :526-528
+                }
+
+                // sediment input coefficients (:549-594)
+                double C_cover_A = C_cover_A0;
+                if (a.dynamic_erod) {
+                    const int dayNo = shared_forcing ? s_doy[dd] : a.doy[d];
+                    double Cs[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const double dmid = q == 0 ? dmid0 : dmid1;
+                        const double dstart = dmid - 60.0 / 2., dend = dmid + 60.0 / 2.;          // :358-359
+                        const double kk = (double)dayNo - dstart;
+                        const bool in_window = kk >= 0.0 && kk == floor(kk) && kk < ceil(dend - dstart)
+                                               && dstart + kk == (double)dayNo;                   // :567
+                        double v = C_out;
+                        if (in_window)
+                            v = ((double)dayNo < dmid)
+                                ? C_cover_A0 + (1.0 - C_cover_A0) * (dayNo - dstart) / (dmid - dstart)   // :569-570
+                                : 1.0 + (C_cover_A0 - 1.0) * (dayNo - dmid) / (dend - dmid);             // :572-573
+                        Cs[q] = v;
+                    }
+                    C_cover_A = f_spr * Cs[0] + (1 - f_spr) * Cs[1];                              // :579-580
+                }
+                const double Esus_A = EA_fac * C_cover_A;
+
+                double EPC0_A, EPC0_NC;
+                if (a.dynamic_epc0) {
+                    EPC0_A = __builtin_fmax(Plab_A / KfMsoil, 0.0);                               // :602
+                    EPC0_NC = __builtin_fmax(Plab_NC / KfMsoil, 0.0);                             // :603
+                } else {
+                    EPC0_A = EPC0_0_A;                                                            // :607
+                    EPC0_NC = (nc_type == 2) ? EPC0_0_A : EPC0_0_S;                               // :608-611
+                }
+
+                // ---- day constants of the right-hand side ----
+                c.c0 = P * (1 - f_quick);
+                c.aE = alpha * PET;
+                c.qin = Qq + QrUS;
+                c.Esum = f_Ar * Esus_A + f_IG * Esus_IG + f_S * Esus_S;
+                c.MsusUS = MsusUS;
+                {
+                    const double tNC = c.omb * wNC * conc_NC;             // soil-water TDP via QsNC (:156-157)
+                    c.tA = c.omb * wA * conc_A + (nc_type == 1 ? tNC : 0.0);
+                    c.tS = (nc_type == 1 ? 0.0 : tNC);
+                    c.tconst = Qq * (wA * conc_A + wNC * conc_NC) + TDPeff + TDPrUS;      // :159-165
+                }
+                {
+                    const double pA = (Plab_A + P_inactive) / Msoil, pN = (Plab_NC + P_inactive) / Msoil;
+                    const double p0 = P_inactive / Msoil;
+                    c.cPP = E_PP * (f_Ar * Esus_A * ((1 - f_NC_Ar) * pA + f_NC_Ar * pN)
+                                    + f_IG * Esus_IG * ((1 - f_NC_IG) * pA + f_NC_IG * pN)
+                                    + f_S * Esus_S * ((1 - f_NC_S) * p0 + f_NC_S * pN));           // :171-176
+                }
+                c.PPrUS = PPrUS;
+
+                // ---- integrate the day (replaces odeint, model.py:640) ----
+                double yq[4] = {0.0, 0.0, 0.0, 0.0};                                              // :618
+                if (INTEG == SIMPLYP_INTEG_RK4) {
+                    rk4_day(y, yq, c, a.step_len, a.substeps);
+                    n_rhs += 4u * (unsigned)a.substeps; n_steps += (unsigned)a.substeps;
+                } else {
+                    CkCounters cnt = {0u, 0u, 0u, false, false};
+                    ck_day(y, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
+                    n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected;
+                    if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
+                    if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
+                }
+                if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));    // Vr = Kv Qr^(1-b_Q), see oracle
+                {
+                    bool fin = true;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) fin = fin && (__builtin_fabs(y[i]) < 1.0e300);
+                    if (!fin) stat |= SIMPLYP_STATUS_NONFINITE;
+                }
+                const double Vg_ode = y[2];                                                       // stored 'Vg' (:644)
+
+                // ---- end-of-day explicit flows and resets (:663-670) ----
+                const double uA = y[0] - fc, uS = y[1] - fc;
+                const double QsA = uA * gate(uA, c.inv_d) / T_s_A;                                // :663
+                const double QsS = uS * gate(uS, c.inv_d) / T_s_S;                                // :664
+                const double ug = y[2] / T_g - Qg_min;
+                const double Qg = Qg_min + gate(ug, c.inv_dg) * ug;                               // :668-669
+                y[2] = Qg * T_g;                                                                  // :670
+
+                // ---- soil P (:676-715) ----
+                const double VsNC = (nc_leak == 1) ? y[0] : y[1];
+                const double QsNC = (nc_leak == 1) ? QsA : QsS;
+                if (a.dynamic_epc0) {
+                    soil_p_update(PnetA, A_catch, KfMsoil, EPC0_A, QsA, Qq, y[0], TDPs_A, Plab_A);       // :688-689
+                    soil_p_update(PnetNC, A_catch, KfMsoil, EPC0_NC, QsNC, Qq, VsNC, TDPs_NC, Plab_NC);  // :692-693
+                    conc_A = TDPs_A / y[0];                                                       // :702
+                    conc_NC = TDPs_NC / VsNC;                                                     // :703
+                } else {
+                    conc_A = EPC0_A;                                                              // :711
+                    conc_NC = EPC0_NC;                                                            // :715
+                }
+
+                // ---- hand the daily series downstream and store the requested columns ----
+                if (active) {
+                    if (route_w) {
+                        double* r = route_w + (size_t)d * E + e;
+                        r[0] = yq[0]; r[(size_t)D * E] = yq[1]; r[(size_t)2 * D * E] = yq[2]; r[(size_t)3 * D * E] = yq[3];
+                    }
+                    if (oslot >= 0) {
+                        const size_t col_stride = (size_t)D * a.n_out_reaches * E;
+                        double* o = a.out + ((size_t)d * a.n_out_reaches + oslot) * E + e;
+                        unsigned m = a.out_mask;
+#define PUT(col, val) if (m & (1u << (col))) { *o = (val); o += col_stride; }
+                        PUT(SIMPLYP_OUT_VSA, y[0]) PUT(SIMPLYP_OUT_VSS, y[1]) PUT(SIMPLYP_OUT_VG, Vg_ode)
+                        PUT(SIMPLYP_OUT_VR, y[3]) PUT(SIMPLYP_OUT_QR_END, y[4]) PUT(SIMPLYP_OUT_QR, yq[0])
+                        PUT(SIMPLYP_OUT_MSUS_END, y[5]) PUT(SIMPLYP_OUT_MSUS_FLUX, yq[1])
+                        PUT(SIMPLYP_OUT_TDPR_END, y[6]) PUT(SIMPLYP_OUT_TDP_FLUX, yq[2])
+                        PUT(SIMPLYP_OUT_PPR_END, y[7]) PUT(SIMPLYP_OUT_PP_FLUX, yq[3])
+                        PUT(SIMPLYP_OUT_QQ, Qq) PUT(SIMPLYP_OUT_QSA, QsA) PUT(SIMPLYP_OUT_QSS, QsS) PUT(SIMPLYP_OUT_QG, Qg)
+                        PUT(SIMPLYP_OUT_C_COVER_A, C_cover_A) PUT(SIMPLYP_OUT_EPC0_A, EPC0_A) PUT(SIMPLYP_OUT_EPC0_NC, EPC0_NC)
+                        PUT(SIMPLYP_OUT_TDPS_A, TDPs_A) PUT(SIMPLYP_OUT_PLAB_A, Plab_A) PUT(SIMPLYP_OUT_CONC_TDPS_A, conc_A)
+                        PUT(SIMPLYP_OUT_TDPS_NC, TDPs_NC) PUT(SIMPLYP_OUT_PLAB_NC, Plab_NC) PUT(SIMPLYP_OUT_CONC_TDPS_NC, conc_NC)
+#undef PUT
+                    }
+                }
+            }
+        }
+    }
+#undef MPv
+#undef RPv
+
+    // ---- per-wave solver statistics and member status ----
+    if (!active) { n_rhs = 0; n_steps = 0; n_rej = 0; }
+    unsigned long long v0 = n_rhs, v1 = n_steps, v2 = n_rej;
+    for (int off = 32; off > 0; off >>= 1) {
+        v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&a.counters[0], v0); atomicAdd(&a.counters[1], v1); atomicAdd(&a.counters[2], v2);
+    }
+    if (active && stat) atomicOr(&a.status[e], stat);
+}
+
+}  // namespace simplyp

@@ -1,0 +1,231 @@
+"""ctypes binding of libsimplyp_hip.so (the C ABI in include/simplyp.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` into
+``simplyp_amd/csrc/libsimplyp_hip.so``.  There is no CPU fallback: if the library
+or a HIP device is missing, every entry point here raises.
+
+torch is used for plumbing only: device buffers, the current HIP stream and
+(in ensemble.py) ``torch.distributed``.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libsimplyp_hip.so')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+
+# every symbol include/simplyp.h declares
+ABI_SYMBOLS = ['simplyp_abi_version', 'simplyp_device_count', 'simplyp_ctx_create', 'simplyp_ctx_destroy',
+               'simplyp_last_error', 'simplyp_ctx_set_stream', 'simplyp_out_bytes', 'simplyp_run',
+               'simplyp_run_async', 'simplyp_sync', 'simplyp_plan', 'simplyp_host_alloc', 'simplyp_host_free',
+               'simplyp_device_alloc', 'simplyp_device_free', 'simplyp_memcpy_h2d', 'simplyp_memcpy_d2h']
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, 'simplyp_hip.hip'), os.path.join(CSRC, 'simplyp_kernels.hip.h'),
+            os.path.join(INCLUDE, 'simplyp.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-o', LIB_PATH, srcs[0]]
+    if verbose:
+        cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises EngineError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError("HIP engine library not found at %s -- build it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); "
+                          "there is no CPU fallback" % LIB_PATH)
+    # torch bundles its own HIP runtime (same SONAME as /opt/rocm's): load torch first so that this
+    # library binds to the runtime that owns the process' device tensors and streams.
+    import torch  # noqa: F401
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, dp = C.c_void_p, C.c_void_p, C.c_void_p
+    L.simplyp_abi_version.restype = C.c_int
+    L.simplyp_device_count.restype = C.c_int
+    L.simplyp_ctx_create.restype = C.c_int
+    L.simplyp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.simplyp_ctx_destroy.restype = None
+    L.simplyp_ctx_destroy.argtypes = [vp]
+    L.simplyp_last_error.restype = C.c_char_p
+    L.simplyp_last_error.argtypes = [vp]
+    L.simplyp_ctx_set_stream.restype = C.c_int
+    L.simplyp_ctx_set_stream.argtypes = [vp, vp]
+    L.simplyp_out_bytes.restype = C.c_int64
+    L.simplyp_out_bytes.argtypes = [C.POINTER(abi.Dims), C.POINTER(abi.Opts), C.c_int32]
+    run_args = [vp, C.POINTER(abi.Dims), C.POINTER(abi.Opts), dp, i32p, i32p, dp, dp,
+                C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, dp, i32p]
+    L.simplyp_run.restype = C.c_int
+    L.simplyp_run.argtypes = run_args + [C.POINTER(abi.Stats)]
+    L.simplyp_run_async.restype = C.c_int
+    L.simplyp_run_async.argtypes = run_args
+    L.simplyp_sync.restype = C.c_int
+    L.simplyp_sync.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.simplyp_plan.restype = C.c_int
+    L.simplyp_plan.argtypes = [C.c_int32] + [C.POINTER(C.c_int32)] * 8
+    L.simplyp_host_alloc.restype = vp
+    L.simplyp_host_alloc.argtypes = [C.c_int64]
+    L.simplyp_host_free.restype = None
+    L.simplyp_host_free.argtypes = [vp]
+    L.simplyp_device_alloc.restype = vp
+    L.simplyp_device_alloc.argtypes = [vp, C.c_int64]
+    L.simplyp_device_free.restype = None
+    L.simplyp_device_free.argtypes = [vp, vp]
+    for name in ('simplyp_memcpy_h2d', 'simplyp_memcpy_d2h'):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [vp, vp, vp, C.c_int64]
+    if L.simplyp_abi_version() != abi.ABI_VERSION:
+        raise EngineError("libsimplyp_hip.so has ABI %d, the Python host expects %d -- rebuild"
+                          % (L.simplyp_abi_version(), abi.ABI_VERSION))
+    _lib = L
+    return L
+
+
+def plan(up_ptr, up_idx):
+    """Routing schedule for a reach graph (host only): dict of per-reach int arrays + totals."""
+    up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int32)
+    up_idx = np.ascontiguousarray(up_idx, dtype=np.int32)
+    S = len(up_ptr) - 1
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    nl, ns = C.c_int32(), C.c_int32()
+    arrs = [np.full(S, -2, dtype=np.int32) for _ in range(4)]
+    dummy = np.zeros(1, dtype=np.int32)
+    rc = lib().simplyp_plan(S, ip(up_ptr), ip(up_idx if up_idx.size else dummy), C.byref(nl), C.byref(ns), *[ip(a) for a in arrs])
+    if rc != 0:
+        raise EngineError("simplyp_plan failed (%d): %s" % (rc, lib().simplyp_last_error(None).decode()))
+    return dict(n_launches=nl.value, n_slots=ns.value, launch=arrs[0], chain=arrs[1], pos=arrs[2], route_slot=arrs[3])
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Engine(object):
+    """One device context.  ``run`` takes device tensors (torch) and returns device tensors."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+        self.torch = torch
+        L = lib()
+        if not torch.cuda.is_available() or L.simplyp_device_count() <= 0:
+            raise EngineError("no HIP device visible: the SimplyP engine runs on MI355X only (no CPU fallback)")
+        self.device = int(device)
+        self.tdev = torch.device('cuda', self.device)
+        h = C.c_void_p()
+        rc = L.simplyp_ctx_create(self.device, C.byref(h))
+        if rc != 0:
+            raise EngineError("simplyp_ctx_create(%d) failed (%d): %s"
+                              % (self.device, rc, L.simplyp_last_error(None).decode()))
+        self._h = h
+        self._use_torch_stream = use_torch_stream
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib().simplyp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError("%s failed (%d): %s" % (what, rc, lib().simplyp_last_error(self._h).decode()))
+
+    def to_device(self, a, dtype=None):
+        """numpy / torch -> contiguous device tensor."""
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.tdev)
+            if dtype is not None:
+                t = t.to(dtype)
+            return t.contiguous()
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.tdev).contiguous()
+
+    def run(self, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing_of_member=None,
+            out_reaches=None, out=None):
+        """Integrate every (member, reach) through all days on the device.
+
+        forcing [n_sets,2,D], doy [D], member_params [NP_M,E], reach_params [NP_R,S,E] may be numpy
+        arrays or device tensors.  Returns (out [n_cols,D,n_out_reaches,E] device tensor,
+        status [E] device tensor, stats dict).
+        """
+        torch = self.torch
+        L = lib()
+        f = self.to_device(forcing, torch.float64)
+        dy = self.to_device(doy, torch.int32)
+        mp = self.to_device(member_params, torch.float64)
+        rp = self.to_device(reach_params, torch.float64)
+        fom = None if forcing_of_member is None else self.to_device(forcing_of_member, torch.int32)
+        n_sets, two, D = f.shape
+        npm, E = mp.shape
+        npr, S, E2 = rp.shape
+        from . import marshal
+        if two != 2 or npm != marshal.NP_M or npr != marshal.NP_R or E2 != E or dy.shape[0] != D:
+            raise ValueError("inconsistent array shapes: forcing %s doy %s member_params %s reach_params %s"
+                             % (tuple(f.shape), tuple(dy.shape), tuple(mp.shape), tuple(rp.shape)))
+        up_ptr = _i32(up_ptr)
+        up_idx = _i32(up_idx)
+        if up_ptr.shape[0] != S + 1:
+            raise ValueError("up_ptr must have S+1 entries")
+        oreach = _i32(out_reaches)
+        n_or = S if oreach is None else len(oreach)
+        ncols = bin(opts.out_mask).count('1')
+        dims = abi.Dims(E, S, D, n_sets)
+        if out is None:
+            out = torch.empty((ncols, D, n_or, E), dtype=torch.float64, device=self.tdev)
+        elif tuple(out.shape) != (ncols, D, n_or, E) or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float64 device tensor of shape %s" % ((ncols, D, n_or, E),))
+        assert out.numel() * 8 == L.simplyp_out_bytes(C.byref(dims), C.byref(opts), n_or)
+        status = torch.empty((E,), dtype=torch.int32, device=self.tdev)
+        stats = abi.Stats()
+        with torch.cuda.device(self.tdev):
+            if self._use_torch_stream:
+                self._check(L.simplyp_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                            'simplyp_ctx_set_stream')
+            else:
+                torch.cuda.current_stream().synchronize()
+            ip = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.POINTER(C.c_int32))
+            rc = L.simplyp_run(self._h, C.byref(dims), C.byref(opts), f.data_ptr(), dy.data_ptr(),
+                               None if fom is None else fom.data_ptr(), mp.data_ptr(), rp.data_ptr(),
+                               ip(up_ptr), ip(up_idx), ip(oreach), n_or, out.data_ptr(), status.data_ptr(),
+                               C.byref(stats))
+        self._check(rc, 'simplyp_run')
+        return out, status, stats.as_dict()
+
+
+_engines = {}
+
+
+def get_engine(device=0):
+    """Process-wide engine per device (contexts hold grow-only device scratch)."""
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]

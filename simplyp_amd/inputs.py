@@ -31,17 +31,22 @@ def _resolve_path(path, workbook_path):
     return norm
 
 
-def read_input_data(params_fpath):
+def read_input_data(params_fpath, setup_overrides=None):
     """Read the SimplyP setup workbook, met data and (optional) observations.
 
     Returns the 8-tuple ``(p_SU, dynamic_options, p, p_LU, p_SC, p_struc,
     met_df, obs_dict)`` of reference inputs.py:155, with the same indices,
-    column labels and error cases (:80-83).
+    column labels and error cases (:80-83).  ``setup_overrides`` (extension)
+    replaces entries of the 'Setup' sheet before they are used, e.g.
+    ``{'st_dt': '1981-01-01', 'metdata_fpath': '/data/met.csv'}``; a value of
+    None blanks the entry (NaN), as an empty cell would.
     """
     wb = xlsx.Workbook(params_fpath)
 
     # Setup parameters (ref :44-50)
     p_SU = xlsx.read_excel(wb, 'Setup', index_col=0, usecols="A,C")['Value']
+    for k, v in (setup_overrides or {}).items():
+        p_SU[k] = np.nan if v is None else v
     dynamic_options = p_SU[['Dynamic_EPC0', 'Dynamic_effluent_inputs',
                             'Dynamic_terrestrialP_inputs', 'Dynamic_erodibility']]
 

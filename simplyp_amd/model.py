@@ -1,0 +1,270 @@
+"""SimplyP model entry points on the MI355X engine.
+
+Drop-in for the reference's ``Current_Release/v0-2A/simplyP/model.py``:
+``run_simply_p`` keeps the signature, return types, column names, in-place
+edits of ``p_LU``/``p_SC``, printed lines and error cases of model.py:193-827,
+but the sub-catchment x day loop nest (model.py:365-724) runs as one batched HIP
+launch sequence behind the C ABI (``engine.py``).  ``run_simply_p_ensemble`` is
+the batched entry the reference does not have.
+
+The three scalar helpers ``f_x``, ``discretized_soilP`` and ``ode_f`` are kept
+as plain Python for API compatibility (``__init__.py`` of the reference exports
+them); they are not used by ``run_simply_p``.
+"""
+
+import os
+
+import numpy as np
+import pandas as pd
+
+from . import abi, marshal
+from . import helper_functions as hf
+
+
+# ------------------------------------------------------------------------------------------
+# scalar helpers kept for API compatibility (reference model.py:23-187)
+
+def f_x(x, threshold, reld):
+    """Smooth 0..1 gate above ``threshold`` (reference model.py:23-37)."""
+    d = threshold * reld
+    if x < threshold:
+        return 0
+    if x > threshold + d:
+        return 1
+    s = (x - threshold) / d
+    return -2 * s**3 + 3 * s**2
+
+
+def discretized_soilP(P_netInput, catchment_area, SC, Kf, Msoil, EPC0, Qs, Qq, Vs, TDPs, Plab):
+    """One-day closed-form update of soil-water TDP and labile soil P (reference model.py:39-56)."""
+    a = P_netInput * catchment_area * 100 / 365. + Kf * Msoil * EPC0
+    b = (Kf * Msoil + Qs + Qq) / Vs
+    TDPs = a / b + (TDPs - a / b) * np.exp(-b)
+    b0 = b * Vs
+    if Vs > 0:
+        sorp = Kf * Msoil * (a / b0 - EPC0 + (1 / b) * (TDPs / Vs - a / b0) * (1 - np.exp(-b)))
+    else:
+        sorp = 0.
+    Plab = Plab + sorp
+    return (TDPs, Plab)
+
+
+def ode_f(y, t, ode_params):
+    """Right-hand side of the 12-variable daily system, same argument tuple as the reference
+    (model.py:58-187).  Python convenience only; the engine evaluates this on the GPU."""
+    (P, E, mu, Qq_i, Qr_US_i, Esus_i, Msus_US_i, TDPr_US_i, PPr_US_i,
+     f_A, f_Ar, f_IG, f_S, f_NC_A, f_NC_Ar, f_NC_IG, f_NC_S, NC_type,
+     f_quick, alpha, beta, T_s, T_g, fc, L_reach, A_catch,
+     a_Q, b_Q, E_M, k_M, conc_TDPs_A, conc_TDPs_NC, PlabA_i, PlabNC_i,
+     Msoil, TDPeff, TDPg, E_PP, P_inactive, dynamic_EPC0, Qg_min) = ode_params
+    VsA, VsS, Vg, Vr, Qr = y[0], y[1], y[2], y[3], y[4]
+    Msus, TDPr, PPr = y[6], y[8], y[10]
+    QsA = (VsA - fc) * f_x(VsA, fc, 0.01) / T_s['A']
+    dVsA = P * (1 - f_quick) - alpha * E * (1 - np.exp(-mu * VsA)) - QsA
+    QsS = (VsS - fc) * f_x(VsS, fc, 0.01) / T_s['S']
+    dVsS = P * (1 - f_quick) - alpha * E * (1 - np.exp(-mu * VsS)) - QsS
+    QsNC = QsA if NC_type == 'A' else QsS
+    f_Qg = f_x(Vg / T_g, Qg_min, 0.01)
+    Qg = (1 - f_Qg) * Qg_min + f_Qg * (Vg / T_g)
+    Qsum = f_A * QsA + f_S * QsS
+    dVg = beta * Qsum - Qg
+    inflow = Qq_i + (1 - beta) * Qsum + Qg + Qr_US_i - Qr
+    dQr = inflow * a_Q * (Qr**b_Q) * 86400. / ((1 - b_Q) * L_reach)
+    QrkM = Qr**k_M
+    MA, MS, MIG = Esus_i['A'] * QrkM, Esus_i['S'] * QrkM, Esus_i['IG'] * QrkM
+    out_M, out_T, out_P = (Msus / Vr) * Qr, Qr * (TDPr / Vr), Qr * PPr / Vr
+    dMsus = f_Ar * MA + f_IG * MIG + f_S * MS + Msus_US_i - out_M
+    dTDPr = ((1 - beta) * (f_A * (1 - f_NC_A) * QsA * conc_TDPs_A + f_A * f_NC_A * QsNC * conc_TDPs_NC
+                           + f_S * f_NC_S * QsNC * conc_TDPs_NC)
+             + f_A * (1 - f_NC_A) * Qq_i * conc_TDPs_A + f_A * f_NC_A * Qq_i * conc_TDPs_NC
+             + f_S * f_NC_S * Qq_i * conc_TDPs_NC
+             + Qg * hf.UC_Cinv(TDPg, A_catch) + TDPeff + TDPr_US_i - out_T)
+    dPPr = (E_PP * (f_Ar * (1 - f_NC_Ar) * MA * (PlabA_i + P_inactive) / Msoil
+                    + f_IG * (1 - f_NC_IG) * MIG * (PlabA_i + P_inactive) / Msoil
+                    + f_S * (1 - f_NC_S) * MS * P_inactive / Msoil
+                    + f_Ar * f_NC_Ar * MA * (PlabNC_i + P_inactive) / Msoil
+                    + f_IG * f_NC_IG * MIG * (PlabNC_i + P_inactive) / Msoil
+                    + f_S * f_NC_S * MS * (PlabNC_i + P_inactive) / Msoil)
+            + PPr_US_i - out_P)
+    return np.array([dVsA, dVsS, dVg, inflow, dQr, Qr, dMsus, out_M, dTDPr, out_T, dPPr, out_P])
+
+
+# ------------------------------------------------------------------------------------------
+# post-processing (reference model.py:831-900)
+
+def derived_P_species(df_R, f_TDP):
+    """TP = TDP + PP and SRP = f_TDP * TDP, for fluxes and concentrations (reference model.py:831-847)."""
+    df_R['TP_mgl'] = df_R['TDP_mgl'] + df_R['PP_mgl']
+    df_R['TP_kg/day'] = df_R['TDP_kg/day'] + df_R['PP_kg/day']
+    df_R['SRP_mgl'] = df_R['TDP_mgl'] * f_TDP
+    df_R['SRP_kg/day'] = df_R['TDP_kg/day'] * f_TDP
+    return df_R
+
+
+def sum_to_waterbody(p_struc, n_SC, df_R_dict, f_TDP):
+    """Sum the reaches flagged 'In_final_flux?' into one series (reference model.py:851-900)."""
+    vars_to_sum = ['Q_cumecs', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day']
+    reaches_in_final_flux = p_struc['In_final_flux?'][p_struc['In_final_flux?'] == 1].index.values
+    if len(reaches_in_final_flux) > n_SC:
+        raise ValueError("Mismatch between the number of subcatchments in the 'Setup' parameter sheet \n(parameter 'n_SC') and in the 'Reach_structure' parameter sheet")
+    print('Sub-catchments flowing directly into receiving waterbody: %s' % reaches_in_final_flux)
+    if len(reaches_in_final_flux) > 1:
+        index = df_R_dict[reaches_in_final_flux[0]].index
+        df_summed = pd.DataFrame(
+            {var: np.sum([df_R_dict[r][var].to_numpy(dtype=float) for r in reaches_in_final_flux], axis=0)
+             for var in vars_to_sum}, index=index, columns=vars_to_sum)
+        df_summed['SS_mgl'] = (df_summed['Msus_kg/day'] / df_summed['Q_cumecs']) * (1000. / 86400.)
+        df_summed['TDP_mgl'] = (df_summed['TDP_kg/day'] / df_summed['Q_cumecs']) * (1000. / 86400.)
+        df_summed['PP_mgl'] = (df_summed['PP_kg/day'] / df_summed['Q_cumecs']) * (1000. / 86400.)
+        df_summed = derived_P_species(df_summed, f_TDP)
+        return df_summed
+    else:
+        print('One or fewer reaches were selected to be included in the sum, check your reach structure parameters')
+        return None
+
+
+# ------------------------------------------------------------------------------------------
+# the hot path
+
+def _engine_opts(p_SU, p, dynamic_options, step_len, solver, out_mask):
+    scs = marshal.sc_list(p)
+    return abi.make_opts(solver,
+                         dynamic_epc0=(dynamic_options['Dynamic_EPC0'] == 'y'),
+                         dynamic_erod=(dynamic_options['Dynamic_erodibility'] == 'y'),
+                         run_mode_cal=(p_SU.run_mode == 'cal'),
+                         sc_qr0=scs.index(int(p['SC_Qr0'])),
+                         out_mask=out_mask, step_len=step_len)
+
+
+def _kf_last(p_SU, p_LU, p_SC, p):
+    """Kf as the reference returns it: the value of the last sub-catchment (model.py:449-453, :827)."""
+    SC = marshal.sc_list(p)[-1]
+    if p_SU.run_mode == 'cal':
+        return 10**-6 * (p_LU['A']['SoilPconc'] - p_LU['S']['SoilPconc']) / \
+            hf.UC_Cinv(p_LU['A']['EPC0_init_mgl'], p_SC.loc['A_catch', SC])
+    return p['Kf']
+
+
+def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len=1., solver=None, device=0):
+    """Simple hydrology, sediment and phosphorus model (reference model.py:193-827).
+
+    Same arguments and 4-tuple return ``(df_TC_dict, df_R_dict, Kf, output_dict)`` as the
+    reference.  Extra keyword arguments: ``solver`` (dict overriding ``abi.DEFAULT_SOLVER``:
+    integrator 'cashkarp'|'rk4', rtol, atol, substeps, max_steps, project_vr) and ``device``.
+    ``output_dict`` holds the engine's solver statistics instead of LSODA's infodict.
+    """
+    from . import engine
+
+    # derived parameters, validation, in-place edits of p_LU / p_SC (model.py:311-361)
+    marshal.prologue(p_SU, p_LU, p_SC, p)
+    scs = marshal.sc_list(p)
+    up_ptr, up_idx, up_lists = marshal.topology(p_struc, p)
+    mp = marshal.member_params(p, p_LU, 1)
+    rp = marshal.reach_params(p_SC, p, 1)
+    forcing, doy = marshal.forcing_arrays(met_df)
+    opts = _engine_opts(p_SU, p, dynamic_options, step_len, solver, marshal.MASK_ALL)
+
+    eng = engine.get_engine(device)          # raises when the HIP library / device is missing
+    out_d, status_d, stats = eng.run(forcing, doy, mp, rp, up_ptr, up_idx, opts)
+    out = out_d.cpu().numpy()                # [25, D, S, 1]
+    status = int(status_d.cpu().numpy()[0])
+    marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)
+
+    df_TC_dict, df_R_dict = {}, {}
+    for j, SC in enumerate(scs):
+        print('Starting model run for sub-catchment: %s' % SC)                               # :367
+        if len(up_lists[SC]) > 0:
+            print('Reaches directly upstream of this reach: %s' % up_lists[SC])              # :512
+        else:
+            print('No reaches directly upstream of this reach')                              # :542
+        A_catch = p_SC.loc['A_catch', SC]
+        df_ODE = pd.DataFrame(out[:12, :, j, 0].T, columns=marshal.ODE_COLUMNS, index=met_df.index)       # :736-740
+        df_nonODE = pd.DataFrame(out[12:, :, j, 0].T, columns=marshal.NONODE_COLUMNS, index=met_df.index)  # :742-746
+
+        df_TC = pd.concat([df_ODE[['VsA', 'VsS', 'Vg']], df_nonODE], axis=1)                  # :755
+        df_TC['TDPs_A_mgl'] = hf.UC_C(df_TC['conc_TDPs_A_kgmm'], A_catch)                     # :758
+        df_TC['EPC0_A_mgl'] = hf.UC_C(df_TC['EPC0_A_kgmm'], A_catch)                          # :759
+        df_TC['Plabile_A_mgkg'] = (10**6 * df_TC['P_labile_A_kg'] / (p['Msoil_m2'] * 10**6 * A_catch))   # :760-761
+        if p_SC.loc['NC_type', SC] != 'None':                                                # :764-773
+            if p_SC.loc['NC_type', SC] == 'A':
+                df_TC['VsNC'] = df_TC['VsA']
+                df_TC['QsNC'] = df_TC['QsA']
+            else:
+                df_TC['VsNC'] = df_TC['VsS']
+                df_TC['QsNC'] = df_TC['QsS']
+            df_TC['TDPs_NC_mgl'] = hf.UC_C(df_TC['conc_TDPs_NC_kgmm'], A_catch)
+            df_TC['Plabile_NC_mgkg'] = (10**6 * df_TC['P_labile_NC_kg'] / (p['Msoil_m2'] * 10**6 * A_catch))
+        if p_SU.inc_snowmelt == 'y':                                                         # :775-776
+            df_TC['D_snow'] = met_df['D_snow_end']
+
+        df_R = df_ODE.drop(['VsA', 'VsS', 'Vg'], axis=1)                                      # :779
+        df_R['Q_cumecs'] = df_R['Qr'] * A_catch * 1000 / 86400                                # :784
+        df_R['SS_mgl'] = hf.UC_C(df_R['Msus_kg/day'] / df_R['Qr'], A_catch)                   # :788
+        df_R['TDP_mgl'] = hf.UC_C(df_R['TDP_kg/day'] / df_R['Qr'], A_catch)                   # :789
+        df_R['PP_mgl'] = hf.UC_C(df_R['PP_kg/day'] / df_R['Qr'], A_catch)                     # :790
+        df_R = derived_P_species(df_R, p['f_TDP'])                                            # :793
+
+        df_TC_dict[SC] = df_TC.sort_index(axis=1)                                             # :797-800
+        df_R_dict[SC] = df_R.sort_index(axis=1)
+        print('Finished!\n')                                                                  # :802
+
+    Kf = _kf_last(p_SU, p_LU, p_SC, p)
+    if p_SU.run_mode == 'cal':                                                               # :809-812
+        print("Running in calibration mode; the soil P sorption coefficient has been estimated as %s mm/kg\n" % Kf)
+    else:
+        print("Running in validation or scenario mode, so the soil P sorption coefficient has been read from the parameter file")
+
+    if p_SU.save_output_csvs == 'y':                                                         # :815-825
+        out_dir = p_SU.output_fpath.replace('\\', os.sep) if isinstance(p_SU.output_fpath, str) else p_SU.output_fpath
+        for SC in df_R_dict.keys():
+            df_TC_dict[SC].to_csv(os.path.join(out_dir, "Results_TC_SC%s.csv" % SC))
+            df_R_toSave = df_R_dict[SC].drop(['Msus_EndOfDay', 'PPr_EndOfDay', 'Qr',
+                                              'Qr_EndOfDay', 'TDPr_EndOfDay', 'Vr'], axis=1)
+            df_R_toSave.to_csv(os.path.join(out_dir, "Instream_results_Reach%s.csv" % SC))
+        print('Results saved to csv\n')
+
+    output_dict = dict(stats, member_status=status, solver=dict(abi.DEFAULT_SOLVER, **(solver or {})),
+                       message='MI355X batched engine')
+    return (df_TC_dict, df_R_dict, Kf, output_dict)                                          # :827
+
+
+def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
+                          outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True):
+    """Run an ensemble of parameter sets through the engine in one call.
+
+    ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
+    array broadcastable to [S, E] (reach parameters, ``marshal.PR_NAMES``); parameters not
+    listed take the workbook value for every member.  ``outputs``: list of reference column
+    names (default: the five documented reach outputs, model.py:272-277).  ``out_reaches``:
+    sub-catchment ids to return (default all).
+
+    Returns ``dict(columns, reaches, data[n_cols, D, n_reaches, E], status[E], stats)``; ``data``
+    and ``status`` are numpy arrays, or device tensors when ``to_host`` is False.
+    The caller's ``p_LU``/``p_SC`` are edited in place exactly as by ``run_simply_p``.
+    """
+    from . import engine
+
+    marshal.prologue(p_SU, p_LU, p_SC, p)
+    scs = marshal.sc_list(p)
+    up_ptr, up_idx, _ = marshal.topology(p_struc, p)
+    m_over, r_over = marshal.split_member_reach_overrides(overrides)
+    sizes = {np.asarray(v).shape[-1] for v in list(m_over.values()) + list(r_over.values()) if np.ndim(v) > 0}
+    if n_members is None:
+        if len(sizes) != 1:
+            raise ValueError("cannot infer the ensemble size: give n_members or override arrays of one length")
+        n_members = sizes.pop()
+    E = int(n_members)
+    mp = marshal.member_params(p, p_LU, E, m_over)
+    rp = marshal.reach_params(p_SC, p, E, r_over)
+    forcing, doy = marshal.forcing_arrays(met_df)
+    cols = list(outputs) if outputs is not None else list(marshal.REACH5_COLUMNS)
+    mask = marshal.mask_of_columns(cols)
+    opts = _engine_opts(p_SU, p, dynamic_options, step_len, solver, mask)
+    oreach = None if out_reaches is None else [scs.index(int(r)) for r in out_reaches]
+
+    eng = engine.get_engine(device)
+    out_d, status_d, stats = eng.run(forcing, doy, mp, rp, up_ptr, up_idx, opts, out_reaches=oreach)
+    marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)
+    return dict(columns=marshal.columns_of_mask(mask), reaches=(scs if out_reaches is None else list(out_reaches)),
+                data=out_d.cpu().numpy() if to_host else out_d,
+                status=status_d.cpu().numpy() if to_host else status_d, stats=stats)

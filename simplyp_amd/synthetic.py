@@ -1,0 +1,69 @@
+"""Synthetic ensembles on the Tarland example (the BASELINE.json configurations).
+
+Everything starts from the reference's shipped parameter workbook and 30-year met file (data copies
+under tests/golden/reference_data/, read through the package's own read_input_data), so the bench and
+the full-size tests go through the same host path a user's notebook would.
+"""
+
+import os
+
+import numpy as np
+
+from . import inputs, marshal
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DATA = os.path.join(REPO, 'tests', 'golden', 'reference_data')
+WORKBOOK = os.path.join(REF_DATA, 'Parameters_v0-2A_Tarland.xlsx')
+MET_CSV = os.path.join(REF_DATA, 'Tarland_MetData_1981-2010.csv')
+
+C3_SEED = 20240601
+
+
+def tarland_inputs(st_dt='1981-01-01', end_dt='2010-12-31', dynamic_epc0='y', dynamic_erod='n', quiet=True):
+    """The reference-shaped inputs of the Tarland example for a period: the 7 arguments of run_simply_p."""
+    import contextlib
+    import io
+    over = dict(metdata_fpath=MET_CSV, Qobsdata_fpath=None, chemObsData_fpath=None, st_dt=st_dt, end_dt=end_dt,
+                Dynamic_EPC0=dynamic_epc0, Dynamic_erodibility=dynamic_erod)
+    with (contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()):
+        p_SU, dyn, p, p_LU, p_SC, p_struc, met_df, _ = inputs.read_input_data(WORKBOOK, setup_overrides=over)
+    return met_df, p_struc, p_SU, p_LU, p_SC, p, dyn
+
+
+def monte_carlo_overrides(p, p_LU, n_members, seed=C3_SEED):
+    """Config C3's parameter distribution: independent draws per member,
+    log-uniform x/÷2 around the base value for T_s[A], T_s[S], T_g, a_Q, E_M, E_PP, TDPg, EPC0_init_mgl[A];
+    uniform +-25 % for fc, beta, f_quick; k_M in [1.5, 2.5], b_Q in [0.3, 0.5], Qg_min in [0, 0.6].
+    Land-use fractions stay fixed (keeps f_A + f_S == 1 exactly)."""
+    rng = np.random.default_rng(seed)
+    E = int(n_members)
+    base = marshal.member_params(p, p_LU, 1)[:, 0]
+    val = lambda name: base[marshal.PM_NAMES.index(name)]
+    over = {}
+    for name in ('T_s_A', 'T_s_S', 'T_g', 'a_Q', 'E_M', 'E_PP', 'TDPg', 'EPC0_init_mgl_A'):
+        over[name] = val(name) * np.exp(rng.uniform(-np.log(2.0), np.log(2.0), E))
+    for name in ('fc', 'beta', 'f_quick'):
+        over[name] = val(name) * rng.uniform(0.75, 1.25, E)
+    over['k_M'] = rng.uniform(1.5, 2.5, E)
+    over['b_Q'] = rng.uniform(0.3, 0.5, E)
+    over['Qg_min'] = rng.uniform(0.0, 0.6, E)
+    return over
+
+
+def c3_problem(n_members, st_dt='1981-01-01', end_dt='2010-12-31', seed=C3_SEED, solver=None,
+               out_mask=marshal.MASK_REACH5, replicated=False):
+    """Arrays + options of the Tarland Monte-Carlo ensemble (BASELINE config C3; `replicated=True` gives
+    config C2: every member = the base parameters).  Returns a dict for Engine.run / oracle.run."""
+    from . import abi
+    met_df, p_struc, p_SU, p_LU, p_SC, p, dyn = tarland_inputs(st_dt, end_dt)
+    marshal.prologue(p_SU, p_LU, p_SC, p)
+    up_ptr, up_idx, _ = marshal.topology(p_struc, p)
+    over = {} if replicated else monte_carlo_overrides(p, p_LU, n_members, seed)
+    mp = marshal.member_params(p, p_LU, n_members, over)
+    rp = marshal.reach_params(p_SC, p, n_members)
+    forcing, doy = marshal.forcing_arrays(met_df)
+    scs = marshal.sc_list(p)
+    opts = abi.make_opts(solver, dynamic_epc0=dyn['Dynamic_EPC0'] == 'y', dynamic_erod=dyn['Dynamic_erodibility'] == 'y',
+                         run_mode_cal=p_SU.run_mode == 'cal', sc_qr0=scs.index(int(p['SC_Qr0'])), out_mask=out_mask)
+    return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx,
+                opts=opts, met=met_df)

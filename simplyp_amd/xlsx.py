@@ -162,4 +162,5 @@ def read_excel(path, sheet_name, index_col=None, usecols=None):
     df = pd.DataFrame(body, columns=header)
     if index_col is not None:
         df = df.set_index(df.columns[index_col])
+        df.columns = pd.Index(list(df.columns))      # re-infer the label dtype (e.g. int sub-catchment ids)
     return df

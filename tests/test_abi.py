@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/simplyp.h declares; the ctypes
+mirrors match the header's struct layout."""
+
+import ctypes as C
+import os
+import re
+
+from simplyp_amd import abi, engine, marshal
+
+HEADER = os.path.join(os.path.dirname(engine.HERE), 'include', 'simplyp.h')
+
+
+def header_text():
+    with open(HEADER) as fh:
+        return fh.read()
+
+
+def test_library_exports_every_declared_symbol():
+    engine.build()
+    L = engine.lib()
+    declared = set(re.findall(r'\b(simplyp_[a-z0-9_]+)\s*\(', header_text()))
+    assert declared == set(engine.ABI_SYMBOLS), declared ^ set(engine.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.simplyp_abi_version() == abi.ABI_VERSION == int(re.search(r'#define SIMPLYP_ABI_VERSION (\d+)', header_text()).group(1))
+
+
+def test_enums_match_python_tables():
+    txt = header_text()
+    pm = re.search(r'enum \{\s*SIMPLYP_PM_F_QUICK = 0(.*?)SIMPLYP_NP_M', txt, re.S).group(0)
+    assert len(re.findall(r'SIMPLYP_PM_[A-Z0-9_]+', pm)) == marshal.NP_M
+    pr = re.search(r'enum \{\s*SIMPLYP_PR_A_CATCH = 0(.*?)SIMPLYP_NP_R', txt, re.S).group(0)
+    assert len(re.findall(r'SIMPLYP_PR_[A-Z0-9_]+', pr)) == marshal.NP_R
+    out = re.search(r'enum \{\s*SIMPLYP_OUT_VSA = 0(.*?)SIMPLYP_N_OUT', txt, re.S).group(0)
+    assert len(re.findall(r'SIMPLYP_OUT_[A-Z0-9_]+', out)) == marshal.N_OUT == 25
+    assert marshal.MASK_REACH5 == (1 << 3) | (1 << 5) | (1 << 7) | (1 << 9) | (1 << 11)
+
+
+def test_struct_layouts(tmp_path):
+    """ctypes mirrors vs the C compiler's view of include/simplyp.h (sizeof / offsetof of every field)."""
+    import subprocess
+    structs = {'simplyp_dims': abi.Dims, 'simplyp_opts': abi.Opts, 'simplyp_stats': abi.Stats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HEADER, 'int main(void){']
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines += ['return 0;}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-o', str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got['%s.%s' % (cname, f)]) == getattr(cls, f).offset, (cname, f)
+
+
+def test_out_bytes_and_host_argument_errors():
+    L = engine.lib()
+    dims = abi.Dims(100, 3, 366, 1)
+    opts = abi.make_opts(out_mask=marshal.MASK_REACH5)
+    assert L.simplyp_out_bytes(C.byref(dims), C.byref(opts), 0) == 5 * 366 * 3 * 100 * 8
+    assert L.simplyp_out_bytes(C.byref(dims), C.byref(opts), 1) == 5 * 366 * 1 * 100 * 8
+    # no device here: creating a context fails with a message, never a crash
+    h = C.c_void_p()
+    if L.simplyp_device_count() == 0:
+        assert L.simplyp_ctx_create(0, C.byref(h)) < 0
+        assert b'not available' in L.simplyp_last_error(None)

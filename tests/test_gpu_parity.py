@@ -1,0 +1,287 @@
+"""Parity tests proper: the HIP engine, called through the C ABI (simplyp_amd.engine -> libsimplyp_hip.so),
+against the CPU oracle on the same seeded inputs, against the golden fixtures recorded from the reference,
+and -- at BASELINE.json's full sizes -- through size-independent properties.
+
+Tolerances (fp64):
+  * kernel vs oracle, fixed-step RK4 (no data-dependent control flow): 1e-10 relative;
+  * kernel vs oracle, Cash-Karp (identical step-size rule; accept/reject may flip on a rounding difference):
+    1e-8 relative;
+  * kernel vs reference odeint(rtol=atol=1e-12), default solver: 1e-6 relative on every reach output
+    (north_star's bar).
+"""
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import helpers
+import simplyp_amd as sp
+from simplyp_amd import abi, engine, ensemble, marshal, synthetic
+
+pytestmark = pytest.mark.gpu
+
+SCENARIOS = ['tarland_2004_static', 'tarland_2004_dynamic', 'confluence3_nc_2004', 'chain4_val_2004']
+REACH_COLS = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day',
+              'PPr_EndOfDay', 'PP_kg/day']
+FLOOR = 1e-12      # columns that are identically 0 (e.g. NC columns without NC land) compare absolutely
+
+
+def gpu_run(eng, m, **kw):
+    out, status, stats = eng.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'],
+                                 m['up_ptr'], m['up_idx'], m['opts'], **kw)
+    return out.cpu().numpy(), status.cpu().numpy(), stats
+
+
+def cpu_run(oracle_lib, m, **kw):
+    return oracle_lib.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'],
+                          m['up_ptr'], m['up_idx'], m['opts'], **kw)
+
+
+def test_native_library_is_the_one_running(engine0):
+    """The ops fail loudly without the extension; here it must be loaded from the tree."""
+    import os
+    assert os.path.samefile(engine.LIB_PATH, os.path.join(engine.CSRC, 'libsimplyp_hip.so'))
+    with open('/proc/self/maps') as fh:
+        assert 'libsimplyp_hip.so' in fh.read()
+    assert engine.lib().simplyp_device_count() >= 1
+
+
+@pytest.mark.parametrize('name', SCENARIOS)
+@pytest.mark.parametrize('solver,tol', [(dict(integrator='rk4', substeps=32), 1e-10),
+                                        (dict(integrator='rk4', substeps=32, project_vr=0), 1e-10),
+                                        (None, 1e-8),
+                                        (dict(integrator='cashkarp', rtol=1e-6, atol=1e-9, project_vr=0), 1e-8)])
+def test_kernel_matches_oracle(engine0, oracle_lib, name, solver, tol):
+    m = helpers.marshal_scenario(name, E=3, solver=solver)
+    got, status, stats = gpu_run(engine0, m)
+    ref, rstatus, rstats = cpu_run(oracle_lib, m)
+    assert status.max() == 0 and rstatus.max() == 0
+    for ci, c in enumerate(marshal.OUT_COLUMNS):
+        err = helpers.max_rel_err(got[ci], ref[ci], floor=FLOOR)
+        assert err < tol, (c, err)
+    # the step-size controller is mirrored: same number of right-hand-side evaluations
+    assert abs(stats['rhs_evals'] - rstats['rhs_evals']) <= 0.001 * rstats['rhs_evals']
+
+
+@pytest.mark.parametrize('name', SCENARIOS + ['tarland_1981_2010_dynamic'])
+def test_kernel_meets_parity_bar_against_reference(engine0, name):
+    """Default solver vs the reference's equations integrated by odeint(rtol=atol=1e-12): <= 1e-6 relative on
+    all reach outputs, every reach, every day."""
+    m = helpers.marshal_scenario(name)
+    got, status, _ = gpu_run(engine0, m)
+    gold = helpers.golden_tables(name, 'tight')
+    assert status.max() == 0
+    worst = {}
+    for j, sc in enumerate(m['scs']):
+        for c in REACH_COLS:
+            worst[c] = max(worst.get(c, 0.0), helpers.max_rel_err(got[marshal.OUT_COLUMNS.index(c), :, j, 0],
+                                                                  gold['R'][sc][c].values, floor=1e-300))
+    assert max(worst.values()) < 1e-6, worst
+
+
+def test_replicated_ensemble_is_bitwise_identical(engine0):
+    """BASELINE config C2 shape: 1024 members with the base parameters -> every member equals the E=1 run
+    bit for bit (full 25-column output)."""
+    m1 = helpers.marshal_scenario('tarland_2004_dynamic', E=1)
+    mE = helpers.marshal_scenario('tarland_2004_dynamic', E=1024)
+    o1, _, _ = gpu_run(engine0, m1)
+    oE, st, _ = gpu_run(engine0, mE)
+    assert st.max() == 0
+    assert np.array_equal(oE, np.broadcast_to(o1, oE.shape), equal_nan=True)
+
+
+@pytest.mark.parametrize('E', [1, 63, 65, 130])
+def test_ragged_ensemble_sizes(engine0, oracle_lib, E):
+    """E not a multiple of the 64-lane wavefront: tail lanes are masked, nothing is written past E."""
+    m = helpers.marshal_scenario('chain4_val_2004', E=E, solver=dict(integrator='rk4', substeps=16))
+    rng = np.random.default_rng(E)
+    m['member_params'][marshal.PM_NAMES.index('T_g')] *= rng.uniform(0.8, 1.25, E)
+    import torch
+    ncols, D, S = 25, m['forcing'].shape[2], 4
+    guard = torch.full((ncols * D * S * E + 64,), -777.0, dtype=torch.float64, device='cuda')
+    out = guard[:ncols * D * S * E].view(ncols, D, S, E)
+    got, status, _ = gpu_run(engine0, m, out=out)
+    assert (guard[ncols * D * S * E:] == -777.0).all()
+    ref, _, _ = cpu_run(oracle_lib, m)
+    assert helpers.max_rel_err(got, ref, floor=FLOOR) < 1e-10
+
+
+def test_output_selection_is_a_slice_of_the_full_output(engine0):
+    full = helpers.marshal_scenario('confluence3_nc_2004', E=5)
+    got_full, _, _ = gpu_run(engine0, full)
+    cols = ['Qr', 'TDP_kg/day', 'P_labile_NC_kg', 'VsA']
+    part = helpers.marshal_scenario('confluence3_nc_2004', E=5, out_mask=marshal.mask_of_columns(cols))
+    got_part, _, _ = gpu_run(engine0, part, out_reaches=[2, 0])
+    order = marshal.columns_of_mask(marshal.mask_of_columns(cols))      # ascending column id
+    for k, c in enumerate(order):
+        for slot, reach in enumerate([2, 0]):
+            assert np.array_equal(got_part[k, :, slot], got_full[marshal.OUT_COLUMNS.index(c), :, reach]), (c, reach)
+
+
+def test_per_member_forcing_sets(engine0):
+    """n_forcing_sets = 2 with a per-member index: each member equals the single-set run on its forcing."""
+    m = helpers.marshal_scenario('tarland_2004_dynamic', E=6)
+    f2 = m['forcing'].copy()
+    f2[0, 0] *= 1.2
+    f2[0, 1] *= 0.9
+    both = np.concatenate([m['forcing'], f2])
+    fom = np.array([0, 1, 1, 0, 1, 0], dtype=np.int32)
+    a, _, _ = gpu_run(engine0, m)
+    mb = dict(m, forcing=f2)
+    b, _, _ = gpu_run(engine0, mb)
+    mm = dict(m, forcing=both)
+    c, st, _ = gpu_run(engine0, mm, forcing_of_member=fom)
+    assert st.max() == 0
+    for e in range(6):
+        want = (a if fom[e] == 0 else b)[..., e]
+        assert np.array_equal(c[..., e], want, equal_nan=True)
+
+
+def test_status_flags(engine0):
+    m = helpers.marshal_scenario('tarland_2004_static', E=4)
+    m['member_params'][marshal.PM_NAMES.index('T_s_A'), 2] = np.nan
+    got, status, _ = gpu_run(engine0, m)
+    assert status[2] & abi.STATUS_NONFINITE and status[0] == status[1] == status[3] == 0
+    assert np.isnan(got[marshal.OUT_COLUMNS.index('Qr'), -1, 0, 2])
+    assert np.array_equal(got[..., 0], got[..., 3])
+    # a cap of 12 attempts per day cannot hold the tolerance on storm days: the day is finished with one
+    # forced step and the member is flagged (and flagged NONFINITE if that step blew up)
+    m = helpers.marshal_scenario('tarland_2004_static', E=2, solver=dict(max_steps=12))
+    got, status, _ = gpu_run(engine0, m)
+    assert (status & abi.STATUS_STEPCAP).all()
+    assert bool(np.isfinite(got[:12]).all()) == (not (status & abi.STATUS_NONFINITE).any())
+
+
+def test_argument_errors_come_back_as_exceptions(engine0):
+    m = helpers.marshal_scenario('tarland_2004_static', E=2)
+    bad = abi.make_opts(dict(integrator='rk4', substeps=0))
+    with pytest.raises(engine.EngineError, match='substeps'):
+        engine0.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], bad)
+    with pytest.raises(engine.EngineError, match='upstream'):
+        m3 = helpers.marshal_scenario('confluence3_nc_2004', E=2)
+        engine0.run(m3['forcing'], m3['doy'], m3['member_params'], m3['reach_params'],
+                    np.array([0, 1, 1, 1]), np.array([2]), m3['opts'])
+    with pytest.raises(ValueError):
+        engine0.run(m['forcing'][:, :, :100], m['doy'], m['member_params'], m['reach_params'],
+                    m['up_ptr'], m['up_idx'], m['opts'])
+
+
+# ---------------------------------------------------------------------------------------------------
+# the drop-in API
+
+@pytest.mark.parametrize('name', SCENARIOS)
+def test_run_simply_p_drop_in(engine0, name, capsys):
+    """run_simply_p on the reference's inputs: same tables (names, order, index), same in-place edits of
+    p_LU / p_SC, same Kf, same printed lines as the reference produced for the golden run."""
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs(name)
+    df_TC, df_R, Kf, output_dict = sp.run_simply_p(met, p_struc, p_SU, p_LU, p_SC, p, dyn)
+    printed = capsys.readouterr().out
+    info = helpers.meta()[name]
+    gold = helpers.golden_tables(name, 'tight')
+    assert Kf == pytest.approx(info['runs']['tight']['Kf'], rel=1e-15)
+    assert sorted(df_R.keys()) == sorted(gold['R'].keys())
+    for sc in gold['R']:
+        assert list(df_R[sc].columns) == list(gold['R'][sc].columns)
+        assert list(df_TC[sc].columns) == list(gold['TC'][sc].columns)
+        assert df_R[sc].index.equals(met.index)
+        for c in gold['R'][sc].columns:       # all 18 reach columns incl. derived concentrations
+            assert helpers.max_rel_err(df_R[sc][c].values, gold['R'][sc][c].values, floor=1e-300) < 1e-6, (sc, c)
+        for c in gold['TC'][sc].columns:      # soil-water flows sit on the gate's steep flank: 1e-5
+            tol = 2e-5 if c in ('QsA', 'QsS', 'QsNC') else 1e-6
+            assert helpers.max_rel_err(df_TC[sc][c].values, gold['TC'][sc][c].values, floor=1e-9) < tol, (sc, c)
+    for col, rows in info['p_LU_after'].items():
+        for k, v in rows.items():
+            got = p_LU.loc[k, col]
+            assert (np.isnan(got) if v is None else got == pytest.approx(v, rel=1e-15)), (k, col)
+    for col, rows in info['p_SC_after'].items():
+        for k, v in rows.items():
+            got = p_SC.loc[k, int(col)]
+            assert (got == v) if isinstance(v, str) else got == pytest.approx(v, rel=1e-15), (k, col)
+    assert printed == info['runs']['tight']['stdout']
+    assert output_dict['member_status'] == 0 and output_dict['rhs_evals'] > 0
+
+
+def test_run_simply_p_writes_reference_csvs(engine0, tmp_path):
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('tarland_2004_static')
+    p_SU['save_output_csvs'] = 'y'
+    p_SU['output_fpath'] = str(tmp_path)
+    df_TC, df_R, _, _ = sp.run_simply_p(met, p_struc, p_SU, p_LU, p_SC, p, dyn)
+    r = pd.read_csv(tmp_path / 'Instream_results_Reach1.csv', index_col=0)
+    ref = pd.read_csv(helpers.GOLDEN + '/reference_data/Instream_results_Reach1.csv', index_col=0)
+    assert list(r.columns) == list(ref.columns) and len(r) == 366      # the reference's on-disk column set
+    tc = pd.read_csv(tmp_path / 'Results_TC_SC1.csv', index_col=0)
+    assert set(pd.read_csv(helpers.GOLDEN + '/reference_data/Results_TC_SC1.csv', index_col=0).columns) <= set(tc.columns) | {'TDPs_NC_kgmm'}
+
+
+def test_run_simply_p_validation_errors_before_any_launch(engine0):
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('tarland_2004_static')
+    p_SC.loc['f_S', 1] = 0.45
+    with pytest.raises(ValueError, match='Land use proportions do not add to 1'):
+        sp.run_simply_p(met, p_struc, p_SU, p_LU, p_SC, p, dyn)
+
+
+def test_run_simply_p_ensemble_overrides(engine0, oracle_lib):
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('chain4_val_2004')
+    E = 10
+    rng = np.random.default_rng(3)
+    over = {'fc': 290 * rng.uniform(0.8, 1.2, E), 'T_s_A': rng.uniform(1, 4, E),
+            'L_reach': np.array([[3000.], [5000.], [7000.], [10000.]]) * rng.uniform(0.7, 1.3, (1, E))}
+    res = sp.run_simply_p_ensemble(met, p_struc, p_SU, p_LU, p_SC, p, dyn, overrides=over, out_reaches=[4])
+    assert res['columns'] == marshal.REACH5_COLUMNS and res['reaches'] == [4]
+    assert res['data'].shape == (5, 366, 1, E) and res['status'].max() == 0
+    # same thing by hand on the oracle
+    m = helpers.marshal_scenario('chain4_val_2004', E=E, out_mask=marshal.MASK_REACH5)
+    m['member_params'][marshal.PM_NAMES.index('fc')] = over['fc']
+    m['member_params'][marshal.PM_NAMES.index('T_s_A')] = over['T_s_A']
+    m['reach_params'][marshal.PR_NAMES.index('L_reach')] = over['L_reach']
+    ref, _, _ = cpu_run(oracle_lib, m, out_reaches=[3])
+    assert helpers.max_rel_err(res['data'], ref, floor=FLOOR) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE configs C2 / C3: Tarland 1981-2010, 10 957 days)
+
+def test_full_size_monte_carlo_properties(engine0, oracle_lib):
+    """65 536-member Monte-Carlo ensemble over the 30-year series (one full wave per SIMD).
+    Properties that do not depend on size: no member flagged; members do not interact (a permutation of the
+    members permutes the outputs; a shard equals the same members of the unsharded run, bit for bit);
+    Vr stays on the invariant of the reference's equations; a seeded sample of members agrees with the oracle."""
+    import torch
+    E = 65536
+    pr = synthetic.c3_problem(E)
+    eng = engine0
+    out, status, stats = eng.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'],
+                                 pr['up_ptr'], pr['up_idx'], pr['opts'])
+    assert int(status.max()) == 0
+    assert bool(torch.isfinite(out).all())
+    n = E * out.shape[1]
+    assert 60 < stats['rhs_evals'] / n < 400
+    # sample vs oracle
+    rng = np.random.default_rng(42)
+    pick = np.sort(rng.choice(E, 8, replace=False))
+    sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
+    ref, _, _ = cpu_run(oracle_lib, sub, n_threads=8)
+    got = out[..., torch.as_tensor(pick, device=out.device)].cpu().numpy()
+    assert helpers.max_rel_err(got, ref, floor=FLOOR) < 1e-8
+    # permutation invariance + shard == unsharded, on a 4096-member slice
+    sl = np.arange(4096) * 16
+    perm = rng.permutation(len(sl))
+    a = eng.run(pr['forcing'], pr['doy'], pr['member_params'][:, sl[perm]], pr['reach_params'][:, :, sl[perm]],
+                pr['up_ptr'], pr['up_idx'], pr['opts'])[0]
+    assert bool(torch.equal(a, out[..., torch.as_tensor(sl[perm], device=out.device)]))
+    for rank in range(8):
+        lo, hi = ensemble.shard_bounds(E, 8, rank)
+        if rank in (0, 5):
+            b = eng.run(pr['forcing'], pr['doy'], pr['member_params'][:, lo:hi], pr['reach_params'][:, :, lo:hi],
+                        pr['up_ptr'], pr['up_idx'], pr['opts'])[0]
+            assert bool(torch.equal(b, out[..., lo:hi]))
+    # Vr on its invariant: Vr = L Qr_end^(1-b) / (a_Q 86400) needs Qr_EndOfDay -> rerun 256 members with it
+    m = dict(pr, member_params=pr['member_params'][:, :256], reach_params=pr['reach_params'][:, :, :256])
+    m['opts'] = abi.make_opts(dynamic_epc0=True, out_mask=marshal.mask_of_columns(['Vr', 'Qr_EndOfDay']))
+    o2 = eng.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])[0]
+    o2 = o2.cpu().numpy()
+    aQ = m['member_params'][marshal.PM_NAMES.index('a_Q')]
+    bQ = m['member_params'][marshal.PM_NAMES.index('b_Q')]
+    L = m['reach_params'][marshal.PR_NAMES.index('L_reach'), 0]
+    inv = L * o2[1, :, 0, :] ** (1 - bQ) / (aQ * 86400)
+    assert helpers.max_rel_err(o2[0, :, 0, :], inv) < 1e-12
