@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- catchment-days/s of the SimplyP time-stepping engine on MI355X.
+
+Workload (config.workload): BASELINE.json's Tarland Monte-Carlo parameter ensemble (config C3): the shipped
+Tarland workbook + 30-year daily met series (1981-2010, 10 957 days, 1 sub-catchment, Dynamic_EPC0 = 'y'),
+100 000 members per GPU drawn from SURVEY.md section 8(d)'s distribution (seed 20240601 + rank), the five
+documented reach outputs written daily ("REACH-5": Vr, Qr, and the three daily fluxes), fp64, default solver
+(Cash-Karp 5(4), rtol 1e-8: the setting that meets the <= 1e-6 parity bar against odeint(rtol=atol=1e-12)).
+A "step" is one pass of the whole ensemble through all days; inputs are resident in HBM before the timed
+region.  Members shard across GPUs with no data-path collective (weak scaling: every rank integrates its own
+100 000 members); the only exchange is the final gather of per-member summaries to rank 0 over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64
+BYTES_PER_CD_REACH5 = 56         # 5 outputs x 8 B written + 2 forcing values x 8 B read per catchment-day
+MEMBERS_PER_GPU = 100000
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--members', type=int, default=MEMBERS_PER_GPU, help='members per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
+                         % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from simplyp_amd import engine, ensemble, marshal, synthetic
+
+    E = args.members
+    prob = synthetic.c3_problem(E, seed=synthetic.C3_SEED + rank)
+    D = prob['forcing'].shape[2]
+    eng = engine.get_engine(local_rank)
+    dev = [eng.to_device(prob[k]) for k in ('forcing', 'doy', 'member_params', 'reach_params')]
+    out = torch.empty((5, D, 1, E), dtype=torch.float64, device=eng.tdev)
+
+    def one_step():
+        o, status, stats = eng.run(dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], prob['opts'], out=out)
+        summ = ensemble.member_summaries(o)                       # [5, 1, E] per-member totals
+        total = ensemble.gather_to_root(summ, E * world) if world > 1 else summ
+        return status, stats, total
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms, rhs = [], 0
+    for _ in range(args.steps):
+        status, stats, total = one_step()
+        kernel_ms.append(stats['kernel_ms'])
+        rhs = stats['rhs_evals']
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    n_bad = int((status != 0).sum().item())
+
+    if rank == 0:
+        cd_per_step = float(E) * world * D                         # S = 1 reach
+        ms_per_step = elapsed / args.steps * 1e3
+        value = cd_per_step / (elapsed / args.steps)
+        k_ms = float(np.mean(kernel_ms))
+        achieved = BYTES_PER_CD_REACH5 * float(E) * D / (k_ms * 1e-3) / 1e9      # GB/s, this rank's launch
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get('members') == E and tj.get('days') == D:
+                traffic = tj.get('hbm_bytes_per_launch')
+        rhs_per_cd = rhs / (float(E) * D)
+        line = {
+            "metric": "catchment-days/sec (ensemble x reaches x days)", "value": value, "unit": "catchment-days/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Tarland Monte-Carlo parameter ensemble (BASELINE config C3): 1 sub-catchment, "
+                                   "2 land-use soil boxes, 30-yr daily 1981-2010 (10957 d), %d members per GPU, "
+                                   "REACH-5 daily output, Cash-Karp 5(4) rtol=1e-8" % E,
+                       "members_per_gpu": E, "reaches": 1, "days": D, "outputs": marshal.REACH5_COLUMNS,
+                       "solver": {k: getattr(prob['opts'], k) for k in ('integrator', 'rtol', 'atol', 'project_vr')},
+                       "parallelism": "ensemble shards, %d GPU(s), no data-path collective; final gather of "
+                                      "per-member summaries" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "simplyp_chain_kernel<CASHKARP>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_CD_REACH5 * float(E) * D,
+                         "note": "the path is fp64-VALU-bound, not HBM-bound: see fp64_valu"},
+            "fp64_valu": {"rhs_evals_per_catchment_day": rhs_per_cd,
+                          "peak_tflops": FP64_VALU_PEAK_TFLOPS},
+            "members_flagged": n_bad,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(prob, D)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prob, D):
+    """The CPU oracle (a C port of the reference's equations with the same Cash-Karp scheme; the Python
+    reference cannot travel to this box) timed on the host cores, on a bounded sample of the same workload."""
+    from oracle import oracle
+    cores = min(os.cpu_count() or 1, 16)
+    n = 6 * cores                                    # ~0.25 core-seconds per member -> ~25 core-seconds
+    mp = prob['member_params'][:, :n].copy()
+    rp = prob['reach_params'][:, :, :n].copy()
+    t0 = time.perf_counter()
+    out, status, stats = oracle.run(prob['forcing'], prob['doy'], mp, rp, prob['up_ptr'], prob['up_idx'],
+                                    prob['opts'], n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n * D / dt, "unit": "catchment-days/s", "cores": cores, "kind": "port",
+            "sample": "first %d members of the same ensemble, all %d days, %d OpenMP threads, %.1f s wall"
+                      % (n, D, cores, dt)}
+
+
+if __name__ == '__main__':
+    main()
