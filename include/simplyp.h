@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 1
+#define SIMPLYP_ABI_VERSION 3
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -106,6 +106,11 @@ typedef struct {
     double   step_len;       /* integration span per day, model.py:345 (default 1.0)       */
     int32_t  project_vr;     /* 1: at each day end reset Vr to the invariant of the reference's own equations,
                                 L_reach*Qr^(1-b_Q)/(a_Q*86400) (drift control; 0 = integrate Vr literally) */
+    int32_t  balance;        /* member load balancing: 0 off, 1 on, 2 auto (on when the ensemble needs more waves
+                                than the chip holds at once).  A pilot run over the first balance_pilot_days days
+                                measures each member's cost; lane slots then take members by decreasing cost.
+                                Results are unchanged bit for bit (members are independent).              */
+    int32_t  balance_pilot_days;   /* 0 = default (160) */
     int32_t  reserved1;
 } simplyp_opts;
 
@@ -115,7 +120,7 @@ typedef struct {
     uint64_t rejected;       /* rejected steps (Cash-Karp)                                 */
     double   kernel_ms;      /* device time of the launches of this run (HIP events)       */
     int32_t  n_launches;     /* kernel launches issued (one per routing stage)             */
-    int32_t  reserved;
+    int32_t  balanced;       /* 1 when the cost-sorted member order was used (kernel_ms then includes the pilot) */
 } simplyp_stats;
 
 typedef struct simplyp_ctx simplyp_ctx;
@@ -153,6 +158,9 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
  *   out               device  [n_cols][D][n_out_reaches][E] fp64, n_cols = popcount(out_mask),
  *                             columns in ascending SIMPLYP_OUT_* order
  *   member_status     device  [E] int32, OR of SIMPLYP_STATUS_* bits (zeroed by the call)
+ *   member_rhs_evals  device  [E] uint32 or NULL: right-hand-side evaluations spent on each member, summed
+ *                             over its reaches and days (what LSODA's infodict['nfe'] was to the reference's
+ *                             caller; also the key the host sorts members by, see simplyp_amd/engine.py)
  *   stats             host    may be NULL
  *
  * The call is synchronous: it returns after the last kernel has finished.
@@ -162,7 +170,7 @@ int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* 
                 const double* member_params, const double* reach_params,
                 const int32_t* up_ptr, const int32_t* up_idx,
                 const int32_t* out_reaches, int32_t n_out_reaches,
-                double* out, int32_t* member_status, simplyp_stats* stats);
+                double* out, int32_t* member_status, uint32_t* member_rhs_evals, simplyp_stats* stats);
 
 /*
  * simplyp_plan -- the routing schedule simplyp_run will use for a reach graph, without touching a
@@ -183,7 +191,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
                       const double* member_params, const double* reach_params,
                       const int32_t* up_ptr, const int32_t* up_idx,
                       const int32_t* out_reaches, int32_t n_out_reaches,
-                      double* out, int32_t* member_status);
+                      double* out, int32_t* member_status, uint32_t* member_rhs_evals);
 int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats);
 
 /* Host-pinned staging buffers for callers that do not use torch (hipHostMalloc/hipHostFree). */

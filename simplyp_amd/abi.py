@@ -2,7 +2,7 @@
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1
@@ -21,12 +21,13 @@ class Opts(C.Structure):
                 ('rtol', C.c_double), ('atol', C.c_double),
                 ('max_steps', C.c_int32), ('dynamic_epc0', C.c_int32), ('dynamic_erod', C.c_int32),
                 ('run_mode_cal', C.c_int32), ('sc_qr0', C.c_int32), ('out_mask', C.c_uint32),
-                ('step_len', C.c_double), ('project_vr', C.c_int32), ('reserved1', C.c_int32)]
+                ('step_len', C.c_double), ('project_vr', C.c_int32), ('balance', C.c_int32),
+                ('balance_pilot_days', C.c_int32), ('reserved1', C.c_int32)]
 
 
 class Stats(C.Structure):
     _fields_ = [('rhs_evals', C.c_uint64), ('steps', C.c_uint64), ('rejected', C.c_uint64),
-                ('kernel_ms', C.c_double), ('n_launches', C.c_int32), ('reserved', C.c_int32)]
+                ('kernel_ms', C.c_double), ('n_launches', C.c_int32), ('balanced', C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}
@@ -35,7 +36,8 @@ class Stats(C.Structure):
 # Solver settings used when the caller does not choose: Cash-Karp 5(4) with per-thread step
 # control at the tolerance that meets the <= 1e-6 parity bar against odeint(rtol=atol=1e-12)
 # ("Integrator").
-DEFAULT_SOLVER = dict(integrator='cashkarp', substeps=8, rtol=1e-8, atol=1e-10, max_steps=4000, project_vr=1)
+DEFAULT_SOLVER = dict(integrator='cashkarp', substeps=8, rtol=1e-8, atol=1e-10, max_steps=4000, project_vr=1,
+                      balance=2, balance_pilot_days=0)
 
 
 def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=True, sc_qr0=0,
@@ -52,6 +54,8 @@ def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=
     o.atol = float(s['atol'])
     o.max_steps = int(s['max_steps'])
     o.project_vr = int(s['project_vr'])
+    o.balance = int(s['balance'])
+    o.balance_pilot_days = int(s['balance_pilot_days'])
     o.dynamic_epc0 = int(bool(dynamic_epc0))
     o.dynamic_erod = int(bool(dynamic_erod))
     o.run_mode_cal = int(bool(run_mode_cal))

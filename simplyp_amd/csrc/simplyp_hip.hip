@@ -2,10 +2,12 @@
 // schedule, launches.  Built by __graft_entry__.build() into simplyp_amd/csrc/libsimplyp_hip.so.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -30,6 +32,9 @@ struct simplyp_ctx {
     DeviceBuf route;          // [n_slots][4][D][E] fp64
     DeviceBuf sched;          // int32 schedule arrays
     DeviceBuf counters;       // 3 x uint64
+    DeviceBuf balance;        // [E] uint32 pilot counts + [E] int32 permutation
+    int n_simd_slots = 1024;  // CUs x 4 SIMDs: wave slots at one resident wave per SIMD
+    int balanced = 0;         // last run used the cost-sorted member order
     int n_launches = 0;
     bool pending = false;
     std::string error;
@@ -219,6 +224,11 @@ int simplyp_ctx_create(int device, simplyp_ctx** out)
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (err == hipSuccess) { ctx->own_stream = true; err = hipEventCreate(&ctx->ev_start); }
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
+    if (err == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->n_simd_slots = prop.multiProcessorCount * 4;
+    }
     if (err != hipSuccess) {
         fail(nullptr, SIMPLYP_ERR_DEVICE, "context creation on device %d failed: %s", device, hipGetErrorString(err));
         simplyp_ctx_destroy(ctx);
@@ -251,6 +261,7 @@ void simplyp_ctx_destroy(simplyp_ctx* ctx)
     if (ctx->route.ptr) (void)hipFree(ctx->route.ptr);
     if (ctx->sched.ptr) (void)hipFree(ctx->sched.ptr);
     if (ctx->counters.ptr) (void)hipFree(ctx->counters.ptr);
+    if (ctx->balance.ptr) (void)hipFree(ctx->balance.ptr);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -298,7 +309,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
                       const double* member_params, const double* reach_params,
                       const int32_t* up_ptr, const int32_t* up_idx,
                       const int32_t* out_reaches, int32_t n_out_reaches,
-                      double* out, int32_t* member_status)
+                      double* out, int32_t* member_status, uint32_t* member_rhs_evals)
 {
     int rc = check_args(ctx, dims, opts, forcing, member_params, reach_params, up_ptr, out, member_status,
                         out_reaches, n_out_reaches);
@@ -344,6 +355,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(member_status, 0, (size_t)E * sizeof(int32_t), ctx->stream));
+    if (member_rhs_evals) HIP_TRY(ctx, hipMemsetAsync(member_rhs_evals, 0, (size_t)E * sizeof(uint32_t), ctx->stream));
 
     const int* dsched = (const int*)ctx->sched.ptr;
     simplyp::KernelArgs a;
@@ -362,19 +374,66 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     a.run_mode_cal = opts->run_mode_cal; a.sc_qr0 = opts->sc_qr0; a.project_vr = opts->project_vr;
     a.rtol = opts->rtol; a.atol = opts->atol; a.step_len = opts->step_len;
 
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    a.D_stride = D;
+    a.perm = nullptr;
+    a.member_rhs = member_rhs_evals;
     const unsigned gx = (unsigned)((E + simplyp::WAVE - 1) / simplyp::WAVE);
-    for (size_t l = 0; l < sch.launches.size(); ++l) {
-        a.chain_ptr = dsched + off_cptr[l];
-        a.chain_reach = dsched + off_creach[l];
-        const unsigned n_chains = (unsigned)sch.launches[l].chain_ptr.size() - 1u;
-        dim3 grid(gx, n_chains, 1), block(simplyp::WAVE, 1, 1);
-        if (opts->integrator == SIMPLYP_INTEG_RK4)
-            hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_RK4>, grid, block, 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP>, grid, block, 0, ctx->stream, a);
-        HIP_TRY(ctx, hipGetLastError());
+    auto launch_all = [&](const simplyp::KernelArgs& base) -> int {
+        simplyp::KernelArgs k = base;
+        for (size_t l = 0; l < sch.launches.size(); ++l) {
+            k.chain_ptr = dsched + off_cptr[l];
+            k.chain_reach = dsched + off_creach[l];
+            const unsigned n_chains = (unsigned)sch.launches[l].chain_ptr.size() - 1u;
+            dim3 grid(gx, n_chains, 1), block(simplyp::WAVE, 1, 1);
+            if (opts->integrator == SIMPLYP_INTEG_RK4)
+                hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_RK4>, grid, block, 0, ctx->stream, k);
+            else
+                hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP>, grid, block, 0, ctx->stream, k);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        return SIMPLYP_OK;
+    };
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+
+    // ---- load balance (Cash-Karp only: members differ in the steps they need) --------------------
+    // With more waves than the chip holds at once, the run takes as long as the unluckiest SIMD's queue.
+    // A short pilot run measures each member's cost; members are then handed to lane slots in order of
+    // decreasing cost, so (a) the lanes of a wave need similar step counts and (b) the dispatcher starts
+    // the long waves first and back-fills with the short ones (longest-processing-time-first).
+    int pilot_days = opts->balance_pilot_days > 0 ? opts->balance_pilot_days : 160;
+    if (pilot_days > D) pilot_days = D;
+    const bool want_balance = opts->integrator == SIMPLYP_INTEG_CASHKARP && pilot_days * 4 <= D &&
+        (opts->balance == 1 || (opts->balance == 2 && (int)gx > ctx->n_simd_slots));
+    ctx->balanced = 0;
+    if (want_balance) {
+        rc = ensure(ctx, ctx->balance, (size_t)E * (sizeof(uint32_t) + sizeof(int32_t)));
+        if (rc != SIMPLYP_OK) return rc;
+        uint32_t* d_cost = (uint32_t*)ctx->balance.ptr;
+        int32_t* d_perm = (int32_t*)(d_cost + E);
+        HIP_TRY(ctx, hipMemsetAsync(d_cost, 0, (size_t)E * sizeof(uint32_t), ctx->stream));
+        simplyp::KernelArgs p = a;
+        p.D = pilot_days;                 // forcing rows keep their stride of D days
+        p.out_mask = 0u;                  // nothing is written
+        p.member_rhs = d_cost;
+        rc = launch_all(p);
+        if (rc != SIMPLYP_OK) return rc;
+        std::vector<uint32_t> cost((size_t)E);
+        HIP_TRY(ctx, hipMemcpyAsync(cost.data(), d_cost, (size_t)E * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int32_t> perm((size_t)E);
+        std::iota(perm.begin(), perm.end(), 0);
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
+        HIP_TRY(ctx, hipMemcpyAsync(d_perm, perm.data(), (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // the pilot's bookkeeping must not leak into the real run
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(member_status, 0, (size_t)E * sizeof(int32_t), ctx->stream));
+        a.perm = d_perm;
+        ctx->balanced = 1;
     }
+    rc = launch_all(a);
+    if (rc != SIMPLYP_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->n_launches = (int)sch.launches.size();
     ctx->pending = true;
@@ -398,6 +457,7 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->rhs_evals = c[0]; stats->steps = c[1]; stats->rejected = c[2];
         stats->kernel_ms = ms;
         stats->n_launches = ctx->n_launches;
+        stats->balanced = ctx->balanced;
     }
     return SIMPLYP_OK;
 }
@@ -407,10 +467,10 @@ int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* 
                 const double* member_params, const double* reach_params,
                 const int32_t* up_ptr, const int32_t* up_idx,
                 const int32_t* out_reaches, int32_t n_out_reaches,
-                double* out, int32_t* member_status, simplyp_stats* stats)
+                double* out, int32_t* member_status, uint32_t* member_rhs_evals, simplyp_stats* stats)
 {
     int rc = simplyp_run_async(ctx, dims, opts, forcing, doy, forcing_of_member, member_params, reach_params,
-                               up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status);
+                               up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status, member_rhs_evals);
     if (rc != SIMPLYP_OK) return rc;
     return simplyp_sync(ctx, stats);
 }

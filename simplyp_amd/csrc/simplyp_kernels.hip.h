@@ -12,7 +12,9 @@
 //   * met forcing (P, PET, day-of-year) is staged per wavefront through LDS in tiles of
 //     TILE_D days; every lane reads the same LDS word (broadcast, conflict-free).
 //   * all per-member data is ensemble-major: lane e touches base[e], so every global load and
-//     store of a wave is one contiguous 512-byte segment.
+//     store of a wave is one contiguous 512-byte segment (when the host has reordered members for
+//     load balance, parameter loads and output stores become 8-byte gathers/scatters instead; the
+//     kernel is arithmetic-bound by three orders of magnitude, so that costs nothing measurable).
 //   * the right-hand side is the reference's ode_f (model.py:58-187) with everything that is
 //     constant within a day hoisted into `DayConst`; Qr**b_Q and Qr**k_M share one log.
 //   * no MFMA: the system is 12 scalar fluxes, there is no contraction to put on matrix cores.
@@ -28,6 +30,8 @@ constexpr int TILE_D = 256;     // days of forcing staged in LDS at a time (256*
 
 struct KernelArgs {
     int E, S, D, n_sets;
+    int D_stride;                   // row stride of `forcing` in days (D of the full run)
+    const int* perm;                // [E] member handled by each lane slot, or nullptr = identity
     const double* forcing;          // [n_sets][2][D]
     const int* doy;                 // [D]
     const int* forcing_of_member;   // [E] or nullptr
@@ -35,6 +39,7 @@ struct KernelArgs {
     const double* rp;               // [NP_R][S][E]
     double* out;                    // [ncols][D][n_out_reaches][E]
     int* status;                    // [E]
+    unsigned* member_rhs;           // [E] or nullptr: rhs evaluations per member
     unsigned long long* counters;   // rhs, steps, rejected
     double* route;                  // [n_slots][4][D][E] daily series handed downstream
     const int* chain_ptr;           // [n_chains+1]   (this launch)
@@ -374,19 +379,24 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
     __shared__ int s_doy[TILE_D];
 
     const int lane = threadIdx.x;
-    const int e_raw = blockIdx.x * WAVE + lane;
-    const bool active = e_raw < a.E;
-    const int e = active ? e_raw : a.E - 1;           // inactive lanes shadow the last member, store nothing
+    const int slot_raw = blockIdx.x * WAVE + lane;
+    const bool active = slot_raw < a.E;
+    const int slot = active ? slot_raw : a.E - 1;     // inactive lanes shadow the last slot, store nothing
+    // Load balancing (host side, simplyp_hip.hip): lane slots may be handed members in order of expected
+    // cost.  Parameters, outputs and status are addressed by member id e (a gather / scatter of 8-byte
+    // words, a few per day against ~1e5 cycles of arithmetic); the routing series stay in slot order.
+    const int e = a.perm ? a.perm[slot] : slot;
     const size_t E = (size_t)a.E;
     const int S = a.S, D = a.D;
+    const size_t Dst = (size_t)a.D_stride;            // days per forcing row (>= D: the pilot run uses fewer days)
 
 #define MPv(idx) (a.mp[(size_t)(idx) * E + e])
 #define RPv(idx, s) (a.rp[((size_t)(idx) * S + (s)) * E + e])
 
     const int set = a.forcing_of_member ? a.forcing_of_member[e] : 0;
     const bool shared_forcing = (a.forcing_of_member == nullptr);
-    const double* Pser = a.forcing + (size_t)set * 2 * D;
-    const double* Eser = Pser + D;
+    const double* Pser = a.forcing + (size_t)set * 2 * Dst;
+    const double* Eser = Pser + Dst;
 
     // ---- member constants (model.py:349-361, 377-390) ----
     const double fc = MPv(SIMPLYP_PM_FC), f_quick = MPv(SIMPLYP_PM_F_QUICK), alpha = MPv(SIMPLYP_PM_ALPHA);
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
                 double QrUS = 0.0, MsusUS = 0.0, TDPrUS = 0.0, PPrUS = 0.0;
                 for (int k = up_lo; k < up_hi; ++k) {
                     const int u = a.up_idx[k];
-                    const double* r = a.route + (size_t)a.route_slot[u] * 4 * D * E + (size_t)d * E + e;
+                    const double* r = a.route + (size_t)a.route_slot[u] * 4 * D * E + (size_t)d * E + slot;
                     QrUS += r[0] * (RPv(SIMPLYP_PR_A_CATCH, u) / A_catch);                        // :524-525
                     MsusUS += r[(size_t)D * E];
                     TDPrUS += r[(size_t)2 * D * E];
@@ -597,10 +607,10 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
                 // ---- hand the daily series downstream and store the requested columns ----
                 if (active) {
                     if (route_w) {
-                        double* r = route_w + (size_t)d * E + e;
+                        double* r = route_w + (size_t)d * E + slot;
                         r[0] = yq[0]; r[(size_t)D * E] = yq[1]; r[(size_t)2 * D * E] = yq[2]; r[(size_t)3 * D * E] = yq[3];
                     }
-                    if (oslot >= 0) {
+                    if (oslot >= 0 && a.out_mask) {
                         const size_t col_stride = (size_t)D * a.n_out_reaches * E;
                         double* o = a.out + ((size_t)d * a.n_out_reaches + oslot) * E + e;
                         unsigned m = a.out_mask;
@@ -633,6 +643,7 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
         atomicAdd(&a.counters[0], v0); atomicAdd(&a.counters[1], v1); atomicAdd(&a.counters[2], v2);
     }
     if (active && stat) atomicOr(&a.status[e], stat);
+    if (active && a.member_rhs) atomicAdd(&a.member_rhs[e], n_rhs);      // several chains may share a member
 }
 
 }  // namespace simplyp

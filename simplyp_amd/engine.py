@@ -18,7 +18,7 @@ from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libsimplyp_hip.so')
+LIB_PATH = os.environ.get('SIMPLYP_HIP_LIB') or os.path.join(CSRC, 'libsimplyp_hip.so')   # env: experiments only
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 
 # every symbol include/simplyp.h declares
@@ -78,9 +78,9 @@ def lib():
     run_args = [vp, C.POINTER(abi.Dims), C.POINTER(abi.Opts), dp, i32p, i32p, dp, dp,
                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, dp, i32p]
     L.simplyp_run.restype = C.c_int
-    L.simplyp_run.argtypes = run_args + [C.POINTER(abi.Stats)]
+    L.simplyp_run.argtypes = run_args + [vp, C.POINTER(abi.Stats)]
     L.simplyp_run_async.restype = C.c_int
-    L.simplyp_run_async.argtypes = run_args
+    L.simplyp_run_async.argtypes = run_args + [vp]
     L.simplyp_sync.restype = C.c_int
     L.simplyp_sync.argtypes = [vp, C.POINTER(abi.Stats)]
     L.simplyp_plan.restype = C.c_int
@@ -170,12 +170,13 @@ class Engine(object):
         return t.to(self.tdev).contiguous()
 
     def run(self, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing_of_member=None,
-            out_reaches=None, out=None):
+            out_reaches=None, out=None, member_rhs=None):
         """Integrate every (member, reach) through all days on the device.
 
         forcing [n_sets,2,D], doy [D], member_params [NP_M,E], reach_params [NP_R,S,E] may be numpy
         arrays or device tensors.  Returns (out [n_cols,D,n_out_reaches,E] device tensor,
-        status [E] device tensor, stats dict).
+        status [E] device tensor, stats dict).  ``member_rhs``: optional int32 device tensor [E] that
+        receives the per-member count of right-hand-side evaluations.
         """
         torch = self.torch
         L = lib()
@@ -216,7 +217,7 @@ class Engine(object):
             rc = L.simplyp_run(self._h, C.byref(dims), C.byref(opts), f.data_ptr(), dy.data_ptr(),
                                None if fom is None else fom.data_ptr(), mp.data_ptr(), rp.data_ptr(),
                                ip(up_ptr), ip(up_idx), ip(oreach), n_or, out.data_ptr(), status.data_ptr(),
-                               C.byref(stats))
+                               None if member_rhs is None else member_rhs.data_ptr(), C.byref(stats))
         self._check(rc, 'simplyp_run')
         return out, status, stats.as_dict()
 

@@ -285,3 +285,28 @@ def test_full_size_monte_carlo_properties(engine0, oracle_lib):
     L = m['reach_params'][marshal.PR_NAMES.index('L_reach'), 0]
     inv = L * o2[1, :, 0, :] ** (1 - bQ) / (aQ * 86400)
     assert helpers.max_rel_err(o2[0, :, 0, :], inv) < 1e-12
+
+
+@pytest.mark.parametrize('name', ['tarland_2004_dynamic', 'chain4_val_2004', 'confluence3_nc_2004'])
+def test_load_balanced_run_is_bitwise_identical(engine0, name):
+    """opts.balance = 1 (pilot run + cost-sorted lane slots, routing series kept in slot order): outputs,
+    status and per-member work come back in member order and equal the unbalanced run bit for bit."""
+    import torch
+    E = 333
+    m0 = helpers.marshal_scenario(name, E=E, solver=dict(balance=0))
+    rng = np.random.default_rng(17)
+    for pname, lo, hi in (('a_Q', 0.5, 2.0), ('T_s_A', 0.5, 2.0), ('fc', 0.8, 1.2), ('T_g', 0.6, 1.5)):
+        m0['member_params'][marshal.PM_NAMES.index(pname)] *= rng.uniform(lo, hi, E)
+    m0['member_params'][marshal.PM_NAMES.index('T_s_A'), 5] = np.nan          # one poisoned member
+    m1 = dict(m0, opts=abi.make_opts(dict(balance=1, balance_pilot_days=40),
+                                     dynamic_epc0=bool(m0['opts'].dynamic_epc0), dynamic_erod=bool(m0['opts'].dynamic_erod),
+                                     run_mode_cal=bool(m0['opts'].run_mode_cal), sc_qr0=m0['opts'].sc_qr0))
+    w0 = torch.zeros(E, dtype=torch.int32, device='cuda')
+    w1 = torch.zeros(E, dtype=torch.int32, device='cuda')
+    a, sa, st_a = gpu_run(engine0, m0, member_rhs=w0)
+    b, sb, st_b = gpu_run(engine0, m1, member_rhs=w1)
+    assert st_a['balanced'] == 0 and st_b['balanced'] == 1
+    assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(sa, sb) and sa[5] & abi.STATUS_NONFINITE and (np.delete(sa, 5) == 0).all()
+    assert bool(torch.equal(w0, w1)) and st_a['rhs_evals'] == st_b['rhs_evals'] == int(w0.sum())
+    assert int(w0.max()) > 1.2 * int(w0[w0 > 0].min())       # the members really do differ in cost
