@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 3
+#define SIMPLYP_ABI_VERSION 4
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -82,7 +82,12 @@ enum {
 
 typedef enum {
     SIMPLYP_INTEG_RK4 = 0,       /* classical RK4, `substeps` equal steps per day            */
-    SIMPLYP_INTEG_CASHKARP = 1   /* Cash-Karp 5(4) embedded pair, per-thread step control    */
+    SIMPLYP_INTEG_CASHKARP = 1,  /* Cash-Karp 5(4) embedded pair, per-thread step control, on the reference's
+                                    12-variable system as written (ode_f, model.py:58-187)                       */
+    SIMPLYP_INTEG_CASHKARP_AUG = 2 /* same pair and step rule on the augmented form of that system: exp(-mu Vs),
+                                    Qr**b_Q, Qr**k_M carried as extra states through their own exact ODEs and
+                                    re-evaluated every day, Vr taken from its invariant -- no transcendental in
+                                    the right-hand side.  Default.                        */
 } simplyp_integrator;
 
 typedef struct {

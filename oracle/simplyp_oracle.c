@@ -16,8 +16,8 @@
  * The integrator itself is NOT the reference's: the reference calls SciPy odeint = ODEPACK
  * LSODA (scipy is un-vendored; reference pins scipy 1.2.0 in README.md:39, 1.15.3 here) at
  * rtol=0.01 (model.py:640).  LSODA's step/order heuristics are not restated; the oracle
- * integrates the same right-hand side with classical RK4 or Cash-Karp 5(4), the two schemes
- * the device kernel implements.  For the LSODA-at-rtol=0.01 trajectory itself: parity
+ * integrates the same right-hand side with classical RK4 or Cash-Karp 5(4) (literal system, or the
+ * augmented transcendental-free form described at ode_aug), the schemes the device kernel implements.  For the LSODA-at-rtol=0.01 trajectory itself: parity
  * unpinned (the reference's own shipped CSVs pin it only to ~3e-3).
  */
 #include <math.h>
@@ -236,6 +236,137 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
 }
 
 /* ------------------------------------------------------------------------------------- */
+/*
+ * SIMPLYP_INTEG_CASHKARP_AUG -- Cash-Karp on an augmented, transcendental-free form of the same system.
+ *
+ * ode_f spends almost all of its arithmetic on exp(-mu*Vs) (x2, :106,:110) and Qr**b_Q, Qr**k_M (:130,:138).
+ * Each of those is a smooth function of a state variable, so it obeys an ODE that is an exact consequence
+ * of the reference's equations:
+ *     EA = exp(-mu VsA)   ->  dEA/dt = -mu EA dVsA/dt        (same for ES)
+ *     pb = Qr**b_Q        ->  dpb/dt = b_Q pb (dQr/dt) / Qr   (same for pk = Qr**k_M)
+ * and Vr is not a free variable at all: (:127-131) and Vr0 (:457-459) give Vr == L Qr**(1-b_Q) / (a_Q 86400),
+ * i.e. Qr/Vr = pb a_Q 86400 / L.  Carrying EA, ES, pb, pk as four extra Runge-Kutta states (re-evaluated
+ * exactly from VsA, VsS, Qr at the start of every day, pb and pk also every 16 accepted steps within a day,
+ * so they cannot drift) leaves a right-hand side of
+ * ~70 multiply-adds and one reciprocal.  The solution is the same function of time; the truncation error
+ * is of the same order and is held by the same error controller (all 15 integrated components enter the
+ * norm).  State vector z: VsA VsS Vg Qr Msus TDPr PPr EA ES pb pk | Qr_av Msus_out TDP_out PP_out.
+ */
+#define NZ 15
+#define AUG_RESYNC 16
+static void ode_aug(const double* z, const ode_params* p, double invKv, double* dz)
+{
+    double VsA = z[0], VsS = z[1], Vg = z[2], Qr = z[3], Msus = z[4], TDPr = z[5], PPr = z[6];
+    double EA = z[7], ES = z[8], pb = z[9], pk = z[10];
+    double QsA = (VsA - p->fc) * f_x(VsA, p->fc, 0.01) / p->T_s_A;                              /* :105 */
+    double dVsA = p->P * (1 - p->f_quick) - p->alpha * p->E * (1 - EA) - QsA;                   /* :106 */
+    double QsS = (VsS - p->fc) * f_x(VsS, p->fc, 0.01) / p->T_s_S;                              /* :109 */
+    double dVsS = p->P * (1 - p->f_quick) - p->alpha * p->E * (1 - ES) - QsS;                   /* :110 */
+    double QsNC = (p->NC_type == 1) ? QsA : QsS;
+    double f_Qg = f_x(Vg / p->T_g, p->Qg_min, 0.01);
+    double Qg = (1 - f_Qg) * p->Qg_min + f_Qg * (Vg / p->T_g);                                  /* :121-122 */
+    double dVg = p->beta * (p->f_A * QsA + p->f_S * QsS) - Qg;                                  /* :124 */
+    double inflow = p->Qq_i + (1 - p->beta) * (p->f_A * QsA + p->f_S * QsS) + Qg + p->Qr_US_i - Qr;
+    double dQr = inflow * p->a_Q * pb * (8.64 * 10000) / ((1 - p->b_Q) * (p->L_reach));         /* :127-130 */
+    double kap = pb * invKv;                                                                    /* Qr / Vr */
+    double MA = p->Esus_A * pk, MS = p->Esus_S * pk, MIG = p->Esus_IG * pk;                     /* :138 */
+    double oM = Msus * kap, oT = TDPr * kap, oP = PPr * kap;
+    double dMsus = p->f_Ar * MA + p->f_IG * MIG + p->f_S * MS + p->Msus_US_i - oM;              /* :141-145 */
+    double dTDPr = ((1 - p->beta) * (p->f_A * (1 - p->f_NC_A) * QsA * p->conc_TDPs_A
+                                     + p->f_A * p->f_NC_A * QsNC * p->conc_TDPs_NC
+                                     + p->f_S * p->f_NC_S * QsNC * p->conc_TDPs_NC)
+                    + p->f_A * (1 - p->f_NC_A) * p->Qq_i * p->conc_TDPs_A
+                    + p->f_A * p->f_NC_A * p->Qq_i * p->conc_TDPs_NC
+                    + p->f_S * p->f_NC_S * p->Qq_i * p->conc_TDPs_NC
+                    + Qg * (p->TDPg * p->A_catch) + p->TDPeff + p->TDPr_US_i - oT);             /* :154-166 */
+    double dPPr = (p->E_PP * (p->f_Ar * (1 - p->f_NC_Ar) * MA * (p->PlabA_i + p->P_inactive) / p->Msoil
+                              + p->f_IG * (1 - p->f_NC_IG) * MIG * (p->PlabA_i + p->P_inactive) / p->Msoil
+                              + p->f_S * (1 - p->f_NC_S) * MS * p->P_inactive / p->Msoil
+                              + p->f_Ar * p->f_NC_Ar * MA * (p->PlabNC_i + p->P_inactive) / p->Msoil
+                              + p->f_IG * p->f_NC_IG * MIG * (p->PlabNC_i + p->P_inactive) / p->Msoil
+                              + p->f_S * p->f_NC_S * MS * (p->PlabNC_i + p->P_inactive) / p->Msoil)
+                   + p->PPr_US_i - oP);                                                         /* :171-178 */
+    double r = dQr / Qr;
+    dz[0] = dVsA; dz[1] = dVsS; dz[2] = dVg; dz[3] = dQr; dz[4] = dMsus; dz[5] = dTDPr; dz[6] = dPPr;
+    dz[7] = -p->mu * EA * dVsA; dz[8] = -p->mu * ES * dVsS;
+    dz[9] = p->b_Q * pb * r; dz[10] = p->k_M * pk * r;
+    dz[11] = Qr; dz[12] = oM; dz[13] = oT; dz[14] = oP;                                         /* :132,:147,:168,:180 */
+}
+
+/* Same step-size rule as cashkarp_day (the kernel mirrors both).  y is the reference's 12-vector; slot 3
+ * (Vr) is returned on its invariant. */
+static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rtol, double atol,
+                             int max_steps, double* h_carry, integ_stats* st)
+{
+    double k[6][NZ], zt[NZ], zn[NZ], z[NZ];
+    double t = 0.0, h = *h_carry;
+    int attempts = 0, since_sync = 0;
+    const double Kv = p->L_reach / (p->a_Q * 8.64 * 10000), invKv = 1.0 / Kv;
+    if (!(h > 0.0) || h > T) h = T;
+    if (!state_finite(y)) { y[5] = y[7] = y[9] = y[11] = NAN; st->poisoned = 1; return; }
+    z[0] = y[0]; z[1] = y[1]; z[2] = y[2]; z[3] = y[4]; z[4] = y[6]; z[5] = y[8]; z[6] = y[10];
+    z[7] = exp(-p->mu * y[0]); z[8] = exp(-p->mu * y[1]);
+    z[9] = pow(y[4], p->b_Q); z[10] = pow(y[4], p->k_M);
+    z[11] = z[12] = z[13] = z[14] = 0.0;
+    while (t < T) {
+        double rem = T - t, hh = h;
+        if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
+        int last_chance = (attempts + 1 >= max_steps);
+        if (last_chance) hh = rem;
+        ode_aug(z, p, invKv, k[0]);
+        for (int s = 1; s < 6; ++s) {
+            for (int i = 0; i < NZ; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < s; ++j) acc += CK_A[s][j] * k[j][i];
+                zt[i] = z[i] + hh * acc;
+            }
+            ode_aug(zt, p, invKv, k[s]);
+        }
+        st->rhs += 6;
+        double err = 0.0; int bad = 0;
+        for (int i = 0; i < NZ; ++i) {
+            double inc = 0.0, ee = 0.0;
+            for (int s = 0; s < 6; ++s) { inc += CK_B[s] * k[s][i]; ee += CK_E[s] * k[s][i]; }
+            zn[i] = z[i] + hh * inc;
+            double sc = atol + rtol * fmax(fabs(z[i]), fabs(zn[i]));
+            double r = fabs(hh * ee) / sc;
+            if (r > err) err = r;
+        }
+        if (!(err < 1.0e300)) bad = 1;
+        for (int i = 0; i < 11; ++i) if (!(fabs(zn[i]) < 1.0e300)) bad = 1;
+        ++attempts;
+        if (last_chance) st->capped = 1;
+        if (bad && (last_chance || hh <= 1.0e-9 * T)) {
+            for (int i = 0; i < NY; ++i) y[i] = NAN;
+            st->poisoned = 1;
+            *h_carry = h;
+            return;
+        } else if (!bad && (err <= 1.0 || last_chance)) {
+            memcpy(z, zn, sizeof(zn));
+            t = (hh == rem) ? T : t + hh;
+            st->steps++;
+            /* pb, pk ride a neutrally stable manifold (nothing damps their drift from Qr**b, Qr**k), so on a
+             * storm day of 100+ steps the local errors would add up: re-evaluate them every AUG_RESYNC steps */
+            if (++since_sync >= AUG_RESYNC && t < T) {
+                z[9] = pow(z[3], p->b_Q); z[10] = pow(z[3], p->k_M);
+                since_sync = 0;
+            }
+        } else {
+            st->rejected++;
+        }
+        double fac;
+        if (bad) fac = 0.2;
+        else if (err == 0.0) fac = 5.0;
+        else { fac = 0.9 * pow(err, -0.2); if (fac < 0.2) fac = 0.2; if (fac > 5.0) fac = 5.0; }
+        h = hh * fac;
+    }
+    *h_carry = h;
+    y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[6] = z[4]; y[8] = z[5]; y[10] = z[6];
+    y[5] = z[11]; y[7] = z[12]; y[9] = z[13]; y[11] = z[14];
+    y[3] = Kv * pow(y[4], 1.0 - p->b_Q);
+}
+
+/* ------------------------------------------------------------------------------------- */
 /* One member: the SC loop (model.py:365) around the day loop (model.py:491).              */
 
 #define MP(name) (mp[(size_t)SIMPLYP_PM_##name * E + e])
@@ -379,8 +510,10 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
 
             /* model.py:640 -- the one place that is not a restatement (see header) */
             if (n_integ == SIMPLYP_INTEG_RK4) rk4_day(y, &op, o->step_len, o->substeps, st);
+            else if (n_integ == SIMPLYP_INTEG_CASHKARP_AUG)
+                cashkarp_aug_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else cashkarp_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
-            if (o->project_vr) {
+            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG) {
                 /* Drift control (not in the reference).  The reference's own equations (:127-131) imply
                  * dVr = dQr * (1-b_Q) L / (a_Q 86400 Qr^b_Q), and Vr0 (:457-459) starts on that curve, so
                  * Vr == L Qr^(1-b_Q) / (a_Q 86400) for all t; Vr has no restoring term and a one-step

@@ -2,11 +2,13 @@
 
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1
-INTEGRATORS = {'rk4': INTEG_RK4, 'cashkarp': INTEG_CASHKARP, 'ck45': INTEG_CASHKARP}
+INTEG_CASHKARP_AUG = 2
+INTEGRATORS = {'rk4': INTEG_RK4, 'cashkarp': INTEG_CASHKARP, 'ck45': INTEG_CASHKARP,
+               'cashkarp_aug': INTEG_CASHKARP_AUG}
 
 STATUS_NONFINITE = 1
 STATUS_STEPCAP = 2
@@ -34,9 +36,9 @@ class Stats(C.Structure):
 
 
 # Solver settings used when the caller does not choose: Cash-Karp 5(4) with per-thread step
-# control at the tolerance that meets the <= 1e-6 parity bar against odeint(rtol=atol=1e-12)
-# ("Integrator").
-DEFAULT_SOLVER = dict(integrator='cashkarp', substeps=8, rtol=1e-8, atol=1e-10, max_steps=4000, project_vr=1,
+# control on the augmented (transcendental-free) form of the system, at the tolerance that meets
+# the <= 1e-6 parity bar against odeint(rtol=atol=1e-12) with a 10x margin.
+DEFAULT_SOLVER = dict(integrator='cashkarp_aug', substeps=8, rtol=1e-8, atol=1e-10, max_steps=4000, project_vr=1,
                       balance=2, balance_pilot_days=0)
 
 

@@ -179,11 +179,12 @@ int check_args(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* o
                     dims->n_forcing_sets);
     if (!forcing || !mp || !rp || !up_ptr || !out || !status)
         return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
-    if (opts->integrator != SIMPLYP_INTEG_RK4 && opts->integrator != SIMPLYP_INTEG_CASHKARP)
+    if (opts->integrator != SIMPLYP_INTEG_RK4 && opts->integrator != SIMPLYP_INTEG_CASHKARP &&
+        opts->integrator != SIMPLYP_INTEG_CASHKARP_AUG)
         return fail(ctx, SIMPLYP_ERR_ARG, "unknown integrator %d", opts->integrator);
     if (opts->integrator == SIMPLYP_INTEG_RK4 && opts->substeps <= 0)
         return fail(ctx, SIMPLYP_ERR_ARG, "RK4 needs substeps >= 1 (got %d)", opts->substeps);
-    if (opts->integrator == SIMPLYP_INTEG_CASHKARP && (!(opts->rtol > 0.0) || !(opts->atol >= 0.0) || opts->max_steps < 1))
+    if (opts->integrator != SIMPLYP_INTEG_RK4 && (!(opts->rtol > 0.0) || !(opts->atol >= 0.0) || opts->max_steps < 1))
         return fail(ctx, SIMPLYP_ERR_ARG, "Cash-Karp needs rtol > 0, atol >= 0, max_steps >= 1");
     if (!(opts->step_len > 0.0)) return fail(ctx, SIMPLYP_ERR_ARG, "step_len must be > 0");
     if (opts->sc_qr0 < 0 || opts->sc_qr0 >= dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "sc_qr0 out of range");
@@ -387,8 +388,10 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
             dim3 grid(gx, n_chains, 1), block(simplyp::WAVE, 1, 1);
             if (opts->integrator == SIMPLYP_INTEG_RK4)
                 hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_RK4>, grid, block, 0, ctx->stream, k);
-            else
+            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP)
                 hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP>, grid, block, 0, ctx->stream, k);
+            else
+                hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP_AUG>, grid, block, 0, ctx->stream, k);
             HIP_TRY(ctx, hipGetLastError());
         }
         return SIMPLYP_OK;
@@ -403,7 +406,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     // the long waves first and back-fills with the short ones (longest-processing-time-first).
     int pilot_days = opts->balance_pilot_days > 0 ? opts->balance_pilot_days : 160;
     if (pilot_days > D) pilot_days = D;
-    const bool want_balance = opts->integrator == SIMPLYP_INTEG_CASHKARP && pilot_days * 4 <= D &&
+    const bool want_balance = opts->integrator != SIMPLYP_INTEG_RK4 && pilot_days * 4 <= D &&
         (opts->balance == 1 || (opts->balance == 2 && (int)gx > ctx->n_simd_slots));
     ctx->balanced = 0;
     if (want_balance) {

@@ -83,6 +83,28 @@ __device__ __forceinline__ double sp_exp(double x)
     return __builtin_amdgcn_ldexp(p, (int)n);
 }
 
+// Two independent exponentials evaluated in lockstep.  One wave per SIMD is resident (the Cash-Karp
+// stages need ~450 registers), so nothing hides the latency of a dependent fp64 FMA chain except
+// independent work in the same wave: interleaving the two Horner chains does that.
+__device__ __forceinline__ void sp_exp2(double x0, double x1, double& r0, double& r1)
+{
+    const double n0 = __builtin_rint(x0 * 1.4426950408889634);
+    const double n1 = __builtin_rint(x1 * 1.4426950408889634);
+    double a = __builtin_fma(n0, -6.93147180369123816490e-01, x0);
+    double b = __builtin_fma(n1, -6.93147180369123816490e-01, x1);
+    a = __builtin_fma(n0, -1.90821492927058770002e-10, a);
+    b = __builtin_fma(n1, -1.90821492927058770002e-10, b);
+    double p = 1.6059043836821613e-10, q = 1.6059043836821613e-10;
+#define SP_STEP(c) p = __builtin_fma(p, a, c); q = __builtin_fma(q, b, c);
+    SP_STEP(2.08767569878681e-09) SP_STEP(2.505210838544172e-08) SP_STEP(2.755731922398589e-07)
+    SP_STEP(2.7557319223985893e-06) SP_STEP(2.48015873015873e-05) SP_STEP(1.984126984126984e-04)
+    SP_STEP(1.388888888888889e-03) SP_STEP(8.333333333333333e-03) SP_STEP(4.1666666666666664e-02)
+    SP_STEP(1.6666666666666666e-01) SP_STEP(0.5) SP_STEP(1.0) SP_STEP(1.0)
+#undef SP_STEP
+    r0 = __builtin_amdgcn_ldexp(p, (int)n0);
+    r1 = __builtin_amdgcn_ldexp(q, (int)n1);
+}
+
 // 1/x: hardware seed + two Newton steps (full double precision for normal x).
 __device__ __forceinline__ double sp_rcp(double x)
 {
@@ -147,6 +169,8 @@ struct DayConst {
     double tconst;      // quick-flow terms + TDPeff + TDPr_US
     // PP (:171-180)
     double cPP, PPrUS;
+    // augmented form only
+    double invKv;       // a_Q 86400 / L_reach = (Qr/Vr) / Qr**b_Q
 };
 
 // f_x(x, threshold, 0.01) with u = x - threshold and inv_d = 1/(0.01 threshold) (model.py:23-37):
@@ -163,7 +187,8 @@ __device__ __forceinline__ void rhs(const double (&y)[8], const DayConst& c, dou
     const double uA = y[0] - c.fc, uS = y[1] - c.fc;
     const double QsA = uA * gate(uA, c.inv_d) * c.invTsA;                         // :105
     const double QsS = uS * gate(uS, c.inv_d) * c.invTsS;                         // :109
-    const double eA = sp_exp(-c.mu * y[0]), eS = sp_exp(-c.mu * y[1]);
+    double eA, eS;
+    sp_exp2(-c.mu * y[0], -c.mu * y[1], eA, eS);
     dy[0] = __builtin_fma(c.aE, eA - 1.0, c.c0) - QsA;                            // :106
     dy[1] = __builtin_fma(c.aE, eS - 1.0, c.c0) - QsS;                            // :110
     const double Qsum = __builtin_fma(c.fA, QsA, c.fS * QsS);
@@ -173,7 +198,8 @@ __device__ __forceinline__ void rhs(const double (&y)[8], const DayConst& c, dou
     const double Qr = y[4];
     const double inflow = __builtin_fma(c.omb, Qsum, c.qin) + Qg - Qr;            // :127-129
     const double lq = sp_log(Qr);
-    const double pb = sp_exp(c.bQ * lq), pk = sp_exp(c.kM * lq);                  // Qr**b_Q, Qr**k_M
+    double pb, pk;
+    sp_exp2(c.bQ * lq, c.kM * lq, pb, pk);                                        // Qr**b_Q, Qr**k_M
     dy[4] = inflow * c.cQ * pb;                                                   // :130
     dy[3] = inflow;                                                               // :131
     const double qv = Qr * sp_rcp(y[3]);
@@ -216,14 +242,69 @@ __device__ __forceinline__ void rk4_day(double (&y)[8], double (&yq)[4], const D
     }
 }
 
+// The augmented form of the same system (SIMPLYP_INTEG_CASHKARP_AUG; derivation and pinning:
+// oracle/simplyp_oracle.c `ode_aug`): exp(-mu Vs), Qr**b_Q, Qr**k_M are carried as extra states through
+// their exact ODEs, Vr comes from its invariant, so the right-hand side is ~70 multiply-adds and one
+// reciprocal.  State z[11] = VsA VsS Vg Qr Msus TDPr PPr EA ES pb pk.
+struct SysLiteral {
+    static constexpr int NS = 8;
+    static constexpr int RESYNC_EVERY = 0;
+    static __device__ __forceinline__ void resync(double (&)[8], const DayConst&) {}
+    static __device__ __forceinline__ void f(const double (&y)[8], const DayConst& c, double (&dy)[8], double (&q)[4])
+    {
+        rhs(y, c, dy, q);
+    }
+};
+
+struct SysAug {
+    static constexpr int NS = 11;
+    // pb, pk are only neutrally stable about Qr**b_Q, Qr**k_M: re-evaluate them every 16 accepted steps
+    // (a storm day can take 100+), as the oracle does
+    static constexpr int RESYNC_EVERY = 16;
+    static __device__ __forceinline__ void resync(double (&z)[11], const DayConst& c)
+    {
+        const double lq = sp_log(z[3]);
+        sp_exp2(c.bQ * lq, c.kM * lq, z[9], z[10]);
+    }
+    static __device__ __forceinline__ void f(const double (&z)[11], const DayConst& c, double (&dz)[11], double (&q)[4])
+    {
+        const double uA = z[0] - c.fc, uS = z[1] - c.fc;
+        const double QsA = uA * gate(uA, c.inv_d) * c.invTsA;                         // :105
+        const double QsS = uS * gate(uS, c.inv_d) * c.invTsS;                         // :109
+        dz[0] = __builtin_fma(c.aE, z[7] - 1.0, c.c0) - QsA;                          // :106 with EA = exp(-mu VsA)
+        dz[1] = __builtin_fma(c.aE, z[8] - 1.0, c.c0) - QsS;                          // :110
+        const double Qsum = __builtin_fma(c.fA, QsA, c.fS * QsS);
+        const double ug = __builtin_fma(z[2], c.invTg, -c.Qgmin);
+        const double Qg = __builtin_fma(gate(ug, c.inv_dg), ug, c.Qgmin);             // :121-122
+        dz[2] = __builtin_fma(c.beta, Qsum, -Qg);                                     // :124
+        const double Qr = z[3], pb = z[9], pk = z[10];
+        const double inflow = __builtin_fma(c.omb, Qsum, c.qin) + Qg - Qr;            // :127-129
+        const double dQr = inflow * c.cQ * pb;                                        // :130
+        dz[3] = dQr;
+        const double kap = pb * c.invKv;                                              // Qr / Vr on the invariant
+        const double oM = z[4] * kap, oT = z[5] * kap, oP = z[6] * kap;
+        dz[4] = __builtin_fma(c.Esum, pk, c.MsusUS) - oM;                             // :141-145
+        dz[5] = __builtin_fma(c.tA, QsA, __builtin_fma(c.tS, QsS, __builtin_fma(c.tg, Qg, c.tconst))) - oT;   // :154-166
+        dz[6] = __builtin_fma(c.cPP, pk, c.PPrUS) - oP;                               // :171-178
+        dz[7] = -c.mu * z[7] * dz[0];                                                 // d exp(-mu VsA)
+        dz[8] = -c.mu * z[8] * dz[1];
+        const double r = dQr * sp_rcp(Qr);
+        dz[9] = c.bQ * pb * r;                                                        // d Qr**b_Q
+        dz[10] = c.kM * pk * r;                                                       // d Qr**k_M
+        q[0] = Qr; q[1] = oM; q[2] = oT; q[3] = oP;                                   // :132,:147,:168,:180
+    }
+};
+
 // Cash-Karp 5(4), per-lane step control; the rule is documented (and mirrored for the parity
-// tests) in oracle/simplyp_oracle.c `embedded_day`.  Lanes that have reached T idle with a zero
-// step until the slowest lane of the wavefront is done.
+// tests) in oracle/simplyp_oracle.c `cashkarp_day` / `cashkarp_aug_day`.  Lanes that have reached T idle
+// with a zero step until the slowest lane of the wavefront is done.
 struct CkCounters { unsigned rhs, steps, rejected; bool capped, poisoned; };
 
-__device__ __forceinline__ void ck_day(double (&y)[8], double (&yq)[4], const DayConst& c, double T,
+template <class SYS>
+__device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], const DayConst& c, double T,
                                        double rtol, double atol, int max_steps, double& h_carry, CkCounters& cnt)
 {
+    constexpr int NS = SYS::NS;
     constexpr double a21 = 1.0 / 5;
     constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
     constexpr double a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
@@ -235,11 +316,11 @@ __device__ __forceinline__ void ck_day(double (&y)[8], double (&yq)[4], const Da
 
     double t = 0.0, h = h_carry;
     if (!(h > 0.0) || h > T) h = T;
-    int attempts = 0;
+    int attempts = 0, since_sync = 0;
     bool alive = true;
     // a member whose state is already non-finite is not integrated further
 #pragma unroll
-    for (int i = 0; i < 8; ++i) alive = alive && (__builtin_fabs(y[i]) < 1.0e300);
+    for (int i = 0; i < NS; ++i) alive = alive && (__builtin_fabs(y[i]) < 1.0e300);
     if (!alive) {
         cnt.poisoned = true;
 #pragma unroll
@@ -254,43 +335,43 @@ __device__ __forceinline__ void ck_day(double (&y)[8], double (&yq)[4], const Da
         if (last_chance) hh = rem;
         if (!alive) hh = 0.0;
 
-        double k1[8], k2[8], k3[8], k4[8], k5[8], k6[8], kq[4], yt[8];
+        double k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], kq[4], yt[NS];
         double sq[4], eq[4];                          // sum b_s kq_s, sum e_s kq_s
-        rhs(y, c, k1, kq);
+        SYS::f(y, c, k1, kq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = b1 * kq[i]; eq[i] = e1 * kq[i]; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) yt[i] = __builtin_fma(hh, a21 * k1[i], y[i]);
-        rhs(yt, c, k2, kq);
+        for (int i = 0; i < NS; ++i) yt[i] = __builtin_fma(hh, a21 * k1[i], y[i]);
+        SYS::f(yt, c, k2, kq);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) yt[i] = __builtin_fma(hh, __builtin_fma(a31, k1[i], a32 * k2[i]), y[i]);
-        rhs(yt, c, k3, kq);
+        for (int i = 0; i < NS; ++i) yt[i] = __builtin_fma(hh, __builtin_fma(a31, k1[i], a32 * k2[i]), y[i]);
+        SYS::f(yt, c, k3, kq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b3, kq[i], sq[i]); eq[i] = __builtin_fma(e3, kq[i], eq[i]); }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NS; ++i)
             yt[i] = __builtin_fma(hh, __builtin_fma(a41, k1[i], __builtin_fma(a42, k2[i], a43 * k3[i])), y[i]);
-        rhs(yt, c, k4, kq);
+        SYS::f(yt, c, k4, kq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b4, kq[i], sq[i]); eq[i] = __builtin_fma(e4, kq[i], eq[i]); }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NS; ++i)
             yt[i] = __builtin_fma(hh, __builtin_fma(a51, k1[i], __builtin_fma(a52, k2[i], __builtin_fma(a53, k3[i], a54 * k4[i]))), y[i]);
-        rhs(yt, c, k5, kq);
+        SYS::f(yt, c, k5, kq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) eq[i] = __builtin_fma(e5, kq[i], eq[i]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NS; ++i)
             yt[i] = __builtin_fma(hh, __builtin_fma(a61, k1[i], __builtin_fma(a62, k2[i], __builtin_fma(a63, k3[i],
                                   __builtin_fma(a64, k4[i], a65 * k5[i])))), y[i]);
-        rhs(yt, c, k6, kq);
+        SYS::f(yt, c, k6, kq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b6, kq[i], sq[i]); eq[i] = __builtin_fma(e6, kq[i], eq[i]); }
 
         double err = 0.0;
-        double yn[8], yqn[4];
+        double yn[NS], yqn[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const double inc = __builtin_fma(b1, k1[i], __builtin_fma(b3, k3[i], __builtin_fma(b4, k4[i], b6 * k6[i])));
             const double ee = __builtin_fma(e1, k1[i], __builtin_fma(e3, k3[i], __builtin_fma(e4, k4[i],
                               __builtin_fma(e5, k5[i], e6 * k6[i]))));
@@ -307,7 +388,7 @@ __device__ __forceinline__ void ck_day(double (&y)[8], double (&yq)[4], const Da
         // v_max_f64 drops NaNs, so test the new state itself
         bool bad = !(err < 1.0e300);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bad = bad || !(__builtin_fabs(yn[i]) < 1.0e300);
+        for (int i = 0; i < NS; ++i) bad = bad || !(__builtin_fabs(yn[i]) < 1.0e300);
 
         if (alive) {
             ++attempts;
@@ -317,18 +398,19 @@ __device__ __forceinline__ void ck_day(double (&y)[8], double (&yq)[4], const Da
             if (give_up) {
                 // cannot be integrated: poison the state, flag the member, stop
 #pragma unroll
-                for (int i = 0; i < 8; ++i) y[i] = __builtin_nan("");
+                for (int i = 0; i < NS; ++i) y[i] = __builtin_nan("");
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yq[i] = __builtin_nan("");
                 cnt.poisoned = true;
                 alive = false;
             } else if (!bad && (err <= 1.0 || last_chance)) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) y[i] = yn[i];
+                for (int i = 0; i < NS; ++i) y[i] = yn[i];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yq[i] = yqn[i];
                 t = (hh == rem) ? T : t + hh;
                 ++cnt.steps;
+                ++since_sync;
                 alive = t < T;
             } else {
                 ++cnt.rejected;
@@ -342,6 +424,12 @@ __device__ __forceinline__ void ck_day(double (&y)[8], double (&yq)[4], const Da
                 fac = fminf(fmaxf(fac, 0.2f), 5.0f);
             }
             h = hh * (double)fac;
+        }
+        if (SYS::RESYNC_EVERY > 0) {
+            const bool due = alive && since_sync >= SYS::RESYNC_EVERY;
+            if (__any(due)) {
+                if (due) { SYS::resync(y, c); since_sync = 0; }
+            }
         }
     }
     h_carry = h;
@@ -464,6 +552,7 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
         c.cQ = a_Q * (8.64 * 10000) / ((1 - b_Q) * L_reach);
         c.bQ = b_Q; c.kM = k_M;
         c.tg = MPv(SIMPLYP_PM_TDPG) * A_catch;                                                    // :163
+        c.invKv = 1.0 / Kv;
 
         const double slopeA = RPv(SIMPLYP_PR_S_AR, s), slopeIG = RPv(SIMPLYP_PR_S_IG, s), slopeS = RPv(SIMPLYP_PR_S_SN, s);
         const double ES = MPv(SIMPLYP_PM_E_M) * RPv(SIMPLYP_PR_S_REACH, s);
@@ -567,14 +656,29 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
                 if (INTEG == SIMPLYP_INTEG_RK4) {
                     rk4_day(y, yq, c, a.step_len, a.substeps);
                     n_rhs += 4u * (unsigned)a.substeps; n_steps += (unsigned)a.substeps;
-                } else {
+                    if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));    // Vr = Kv Qr^(1-b_Q), see oracle
+                } else if (INTEG == SIMPLYP_INTEG_CASHKARP) {
                     CkCounters cnt = {0u, 0u, 0u, false, false};
-                    ck_day(y, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
+                    ck_day<SysLiteral>(y, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
+                    if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));
+                } else {
+                    // augmented form: the auxiliary states are re-evaluated exactly from VsA, VsS, Qr every day
+                    double z[11];
+                    z[0] = y[0]; z[1] = y[1]; z[2] = y[2]; z[3] = y[4]; z[4] = y[5]; z[5] = y[6]; z[6] = y[7];
+                    sp_exp2(-mu * y[0], -mu * y[1], z[7], z[8]);
+                    const double lq0 = sp_log(y[4]);
+                    sp_exp2(b_Q * lq0, k_M * lq0, z[9], z[10]);
+                    CkCounters cnt = {0u, 0u, 0u, false, false};
+                    ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
+                    n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected;
+                    if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
+                    if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
+                    y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
+                    y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));                  // Vr on its invariant
                 }
-                if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));    // Vr = Kv Qr^(1-b_Q), see oracle
                 {
                     bool fin = true;
 #pragma unroll

@@ -326,6 +326,35 @@ def unit_vectors(mods, rng):
     return out
 
 
+def monte_carlo_members(mods, switch, n=8, years=('2003-01-01', '2005-12-31')):
+    """n members of the BASELINE C3 parameter distribution (simplyp_amd.synthetic.monte_carlo_overrides), each run
+    through the unmodified reference with odeint at rtol=atol=1e-12 -> monte_carlo_members.npz.  Pins the parity bar
+    across the distribution the bench draws from, not just at the workbook's parameter set."""
+    from simplyp_amd import synthetic, marshal
+    sc = scenarios(False)['tarland_2004_dynamic']
+    p_SU, p, p_LU, p_SC, p_struc, met = tarland_inputs(*years)
+    sc = dict(sc, p_SU=p_SU, p=p, p_LU=p_LU, p_SC=p_SC, p_struc=p_struc, met=met,
+              dyn=dict(Dynamic_EPC0='y', Dynamic_erodibility='n'))
+    over = synthetic.monte_carlo_overrides(p, p_LU, n, seed=synthetic.C3_SEED)
+    arrays = {'names': np.array(sorted(over)), 'values': np.array([over[k] for k in sorted(over)])}
+    for e in range(n):
+        s2 = dict(sc, p=sc['p'].copy(), p_LU=sc['p_LU'].copy())
+        for name in over:
+            src = dict(marshal.PM_SPEC)[name]
+            if src[0] == 'p':
+                s2['p'][src[1]] = float(over[name][e])
+            else:
+                s2['p_LU'].loc[src[1], src[2]] = float(over[name][e])
+        r = run_reference(mods, switch, s2, 1e-12)
+        arrays['R/%d' % e] = r['df_R'][1].to_numpy(dtype=float)
+        arrays['R/columns'] = np.array(list(r['df_R'][1].columns))
+        arrays['TC/%d' % e] = r['df_TC'][1].to_numpy(dtype=float)
+        arrays['TC/columns'] = np.array(list(r['df_TC'][1].columns))
+        print('member %d: wall %.1f s  nfe/day %.1f' % (e, r['wall'], r['nfe_per_day']))
+    arrays['years'] = np.array(years)
+    np.savez_compressed(os.path.join(HERE, 'monte_carlo_members.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--long', action='store_true', help='also run the 1981-2010 scenario (minutes)')
@@ -336,6 +365,11 @@ def main():
     switch = OdeintSwitch()
     mods['model'].odeint = switch
     rng = np.random.default_rng(20240601)
+
+    if args.only in (None, 'mc'):
+        monte_carlo_members(mods, switch)
+        if args.only == 'mc':
+            return
 
     if args.only in (None, 'unit'):
         np.savez_compressed(os.path.join(HERE, 'unit_vectors.npz'), **unit_vectors(mods, rng))
