@@ -249,6 +249,8 @@ __device__ __forceinline__ void rk4_day(double (&y)[8], double (&yq)[4], const D
 struct SysLiteral {
     static constexpr int NS = 8;
     static constexpr int RESYNC_EVERY = 0;
+    static constexpr int N_ERR = 8;             // all 8 states and the 4 daily integrals enter the error norm
+    static constexpr bool QUAD_IN_NORM = true;
     static __device__ __forceinline__ void resync(double (&)[8], const DayConst&) {}
     static __device__ __forceinline__ void f(const double (&y)[8], const DayConst& c, double (&dy)[8], double (&q)[4])
     {
@@ -261,6 +263,10 @@ struct SysAug {
     // pb, pk are only neutrally stable about Qr**b_Q, Qr**k_M: re-evaluate them every 16 accepted steps
     // (a storm day can take 100+), as the oracle does
     static constexpr int RESYNC_EVERY = 16;
+    // error norm over the 7 physical states (the auxiliary states are functions of them, the daily integrals
+    // quadratures of them; see oracle/simplyp_oracle.c)
+    static constexpr int N_ERR = 7;
+    static constexpr bool QUAD_IN_NORM = false;
     static __device__ __forceinline__ void resync(double (&z)[11], const DayConst& c)
     {
         const double lq = sp_log(z[3]);
@@ -337,53 +343,74 @@ __device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], co
 
         double k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], kq[4], yt[NS];
         double sq[4], eq[4];                          // sum b_s kq_s, sum e_s kq_s
+        // stage weights premultiplied by the step (per lane): one FMA per (component, earlier stage)
         SYS::f(y, c, k1, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = b1 * kq[i]; eq[i] = e1 * kq[i]; }
+        for (int i = 0; i < 4; ++i) { sq[i] = b1 * kq[i]; if (SYS::QUAD_IN_NORM) eq[i] = e1 * kq[i]; }
+        {
+            const double h21 = hh * a21;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) yt[i] = __builtin_fma(hh, a21 * k1[i], y[i]);
+            for (int i = 0; i < NS; ++i) yt[i] = __builtin_fma(h21, k1[i], y[i]);
+        }
         SYS::f(yt, c, k2, kq);
+        {
+            const double h31 = hh * a31, h32 = hh * a32;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) yt[i] = __builtin_fma(hh, __builtin_fma(a31, k1[i], a32 * k2[i]), y[i]);
+            for (int i = 0; i < NS; ++i) yt[i] = __builtin_fma(h32, k2[i], __builtin_fma(h31, k1[i], y[i]));
+        }
         SYS::f(yt, c, k3, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b3, kq[i], sq[i]); eq[i] = __builtin_fma(e3, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b3, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e3, kq[i], eq[i]); }
+        {
+            const double h41 = hh * a41, h42 = hh * a42, h43 = hh * a43;
 #pragma unroll
-        for (int i = 0; i < NS; ++i)
-            yt[i] = __builtin_fma(hh, __builtin_fma(a41, k1[i], __builtin_fma(a42, k2[i], a43 * k3[i])), y[i]);
+            for (int i = 0; i < NS; ++i)
+                yt[i] = __builtin_fma(h43, k3[i], __builtin_fma(h42, k2[i], __builtin_fma(h41, k1[i], y[i])));
+        }
         SYS::f(yt, c, k4, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b4, kq[i], sq[i]); eq[i] = __builtin_fma(e4, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b4, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e4, kq[i], eq[i]); }
+        {
+            const double h51 = hh * a51, h52 = hh * a52, h53 = hh * a53, h54 = hh * a54;
 #pragma unroll
-        for (int i = 0; i < NS; ++i)
-            yt[i] = __builtin_fma(hh, __builtin_fma(a51, k1[i], __builtin_fma(a52, k2[i], __builtin_fma(a53, k3[i], a54 * k4[i]))), y[i]);
+            for (int i = 0; i < NS; ++i)
+                yt[i] = __builtin_fma(h54, k4[i], __builtin_fma(h53, k3[i], __builtin_fma(h52, k2[i], __builtin_fma(h51, k1[i], y[i]))));
+        }
         SYS::f(yt, c, k5, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) eq[i] = __builtin_fma(e5, kq[i], eq[i]);
+        for (int i = 0; i < 4; ++i) if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e5, kq[i], eq[i]);
+        {
+            const double h61 = hh * a61, h62 = hh * a62, h63 = hh * a63, h64 = hh * a64, h65 = hh * a65;
 #pragma unroll
-        for (int i = 0; i < NS; ++i)
-            yt[i] = __builtin_fma(hh, __builtin_fma(a61, k1[i], __builtin_fma(a62, k2[i], __builtin_fma(a63, k3[i],
-                                  __builtin_fma(a64, k4[i], a65 * k5[i])))), y[i]);
+            for (int i = 0; i < NS; ++i)
+                yt[i] = __builtin_fma(h65, k5[i], __builtin_fma(h64, k4[i], __builtin_fma(h63, k3[i],
+                        __builtin_fma(h62, k2[i], __builtin_fma(h61, k1[i], y[i])))));
+        }
         SYS::f(yt, c, k6, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b6, kq[i], sq[i]); eq[i] = __builtin_fma(e6, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b6, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e6, kq[i], eq[i]); }
 
         double err = 0.0;
         double yn[NS], yqn[4];
+        const double hb1 = hh * b1, hb3 = hh * b3, hb4 = hh * b4, hb6 = hh * b6;
+        const double he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const double inc = __builtin_fma(b1, k1[i], __builtin_fma(b3, k3[i], __builtin_fma(b4, k4[i], b6 * k6[i])));
-            const double ee = __builtin_fma(e1, k1[i], __builtin_fma(e3, k3[i], __builtin_fma(e4, k4[i],
-                              __builtin_fma(e5, k5[i], e6 * k6[i]))));
-            yn[i] = __builtin_fma(hh, inc, y[i]);
-            const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(y[i]), __builtin_fabs(yn[i])), atol);
-            err = __builtin_fmax(err, __builtin_fabs(hh * ee) * __builtin_amdgcn_rcp(sc));
+            yn[i] = __builtin_fma(hb6, k6[i], __builtin_fma(hb4, k4[i], __builtin_fma(hb3, k3[i], __builtin_fma(hb1, k1[i], y[i]))));
+            if (i < SYS::N_ERR) {
+                const double he = __builtin_fma(he1, k1[i], __builtin_fma(he3, k3[i], __builtin_fma(he4, k4[i],
+                                  __builtin_fma(he5, k5[i], he6 * k6[i]))));
+                const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(y[i]), __builtin_fabs(yn[i])), atol);
+                err = __builtin_fmax(err, __builtin_fabs(he) * __builtin_amdgcn_rcp(sc));
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             yqn[i] = __builtin_fma(hh, sq[i], yq[i]);
-            const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(yq[i]), __builtin_fabs(yqn[i])), atol);
-            err = __builtin_fmax(err, __builtin_fabs(hh * eq[i]) * __builtin_amdgcn_rcp(sc));
+            if (SYS::QUAD_IN_NORM) {
+                const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(yq[i]), __builtin_fabs(yqn[i])), atol);
+                err = __builtin_fmax(err, __builtin_fabs(hh * eq[i]) * __builtin_amdgcn_rcp(sc));
+            }
         }
         // v_max_f64 drops NaNs, so test the new state itself
         bool bad = !(err < 1.0e300);
