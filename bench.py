@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--members', type=int, default=MEMBERS_PER_GPU, help='members per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the accuracy check (keeps a profile to one kernel shape)')
     args = ap.parse_args()
 
     import numpy as np
@@ -55,7 +56,9 @@ def main():
     from simplyp_amd import engine, ensemble, marshal, synthetic
 
     E = args.members
-    prob = synthetic.c3_problem(E, seed=synthetic.C3_SEED + rank)
+    # outputs stay in lane-slot order (fully coalesced stores) + the member id of every slot: what a consumer of a
+    # load-balanced run gets; the per-member summaries below are put back into member order before the gather
+    prob = synthetic.c3_problem(E, seed=synthetic.C3_SEED + rank, solver=dict(out_slot_order=1))
     D = prob['forcing'].shape[2]
     eng = engine.get_engine(local_rank)
     dev = [eng.to_device(prob[k]) for k in ('forcing', 'doy', 'member_params', 'reach_params')]
@@ -63,7 +66,9 @@ def main():
 
     def one_step():
         o, status, stats = eng.run(dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], prob['opts'], out=out)
-        summ = ensemble.member_summaries(o)                       # [5, 1, E] per-member totals
+        by_slot = ensemble.member_summaries(o)                    # [5, 1, E] per-slot totals
+        summ = torch.empty_like(by_slot)
+        summ[..., stats['member_of_slot'].long()] = by_slot       # -> member order
         total = ensemble.gather_to_root(summ, E * world) if world > 1 else summ
         return status, stats, total
 
@@ -109,19 +114,21 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Tarland Monte-Carlo parameter ensemble (BASELINE config C3): 1 sub-catchment, "
                                    "2 land-use soil boxes, 30-yr daily 1981-2010 (10957 d), %d members per GPU, "
-                                   "REACH-5 daily output, Cash-Karp 5(4) rtol=1e-8" % E,
+                                   "REACH-5 daily output, Cash-Karp 5(4) on the augmented system, rtol=1e-8" % E,
                        "members_per_gpu": E, "reaches": 1, "days": D, "outputs": marshal.REACH5_COLUMNS,
                        "solver": {k: getattr(prob['opts'], k) for k in ('integrator', 'rtol', 'atol', 'project_vr')},
                        "parallelism": "ensemble shards, %d GPU(s), no data-path collective; final gather of "
                                       "per-member summaries" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "simplyp_chain_kernel<CASHKARP>", "kernel_ms": k_ms,
+                         "kernel": "simplyp_chain_kernel<%d>" % prob['opts'].integrator, "kernel_ms": k_ms,
+                         "pilot_ms": stats.get('pilot_ms', 0.0),
                          "algorithmic_bytes_per_launch": BYTES_PER_CD_REACH5 * float(E) * D,
                          "note": "the path is fp64-VALU-bound, not HBM-bound: see fp64_valu"},
             "fp64_valu": {"rhs_evals_per_catchment_day": rhs_per_cd,
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS},
             "members_flagged": n_bad,
+            "parity": None if args.no_parity else parity_check(eng, prob['opts']),
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(prob, D)
@@ -131,12 +138,34 @@ def main():
         dist.destroy_process_group()
 
 
+def parity_check(eng, opts):
+    """Accuracy that goes with the throughput number: the Tarland 1981-2010 base member through the same
+    kernel and solver settings, against the reference's own equations integrated by odeint(rtol=atol=1e-12)
+    (tests/golden/tarland_1981_2010_dynamic.npz, recorded from the unmodified reference)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    from simplyp_amd import marshal
+    name = 'tarland_1981_2010_dynamic'
+    m = helpers.marshal_scenario(name, E=64)
+    for k in ('integrator', 'substeps', 'rtol', 'atol', 'max_steps', 'project_vr'):
+        setattr(m['opts'], k, getattr(opts, k))
+    m['opts'].out_slot_order = 0
+    out, status, _ = eng.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])
+    got = out[..., 0].cpu().numpy()
+    gold = helpers.golden_tables(name, 'tight')['R'][1]
+    cols = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
+    rel = np.concatenate([np.abs(got[marshal.OUT_COLUMNS.index(c), :, 0] - gold[c].values) / np.abs(gold[c].values) for c in cols])
+    return {"max_rel_err": float(rel.max()), "p99_rel_err": float(np.percentile(rel, 99)), "bar": 1e-6,
+            "columns": "9 reach outputs x 10957 days", "against": "reference ode_f + driver, odeint rtol=atol=1e-12 (golden fixture)"}
+
+
 def cpu_baseline(prob, D):
     """The CPU oracle (a C port of the reference's equations with the same Cash-Karp scheme; the Python
     reference cannot travel to this box) timed on the host cores, on a bounded sample of the same workload."""
     from oracle import oracle
     cores = min(os.cpu_count() or 1, 16)
-    n = 6 * cores                                    # ~0.25 core-seconds per member -> ~25 core-seconds
+    n = 16 * cores                                   # ~0.08 core-seconds per member-30-years -> ~20 core-seconds
     mp = prob['member_params'][:, :n].copy()
     rp = prob['reach_params'][:, :, :n].copy()
     t0 = time.perf_counter()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 4
+#define SIMPLYP_ABI_VERSION 5
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -116,16 +116,20 @@ typedef struct {
                                 measures each member's cost; lane slots then take members by decreasing cost.
                                 Results are unchanged bit for bit (members are independent).              */
     int32_t  balance_pilot_days;   /* 0 = default (160) */
-    int32_t  reserved1;
+    int32_t  out_slot_order; /* 0: `out` is written in member order (when members were reordered for balance this is
+                                a scatter of 8-byte words: correct, but HBM sees ~4x the output bytes as partial-sector
+                                writes).  1: `out` is written in lane-slot order, fully coalesced, and the caller gets
+                                the member id of every slot in `member_of_slot` (identity when no reordering happened) */
 } simplyp_opts;
 
 typedef struct {
     uint64_t rhs_evals;      /* right-hand-side evaluations, all members/reaches/days      */
     uint64_t steps;          /* accepted steps                                             */
     uint64_t rejected;       /* rejected steps (Cash-Karp)                                 */
-    double   kernel_ms;      /* device time of the launches of this run (HIP events)       */
+    double   kernel_ms;      /* device time of the main launches of this run (HIP events on the run's stream) */
+    double   pilot_ms;       /* load balancing: pilot launches + host sort of the cost keys (0 when off)      */
     int32_t  n_launches;     /* kernel launches issued (one per routing stage)             */
-    int32_t  balanced;       /* 1 when the cost-sorted member order was used (kernel_ms then includes the pilot) */
+    int32_t  balanced;       /* 1 when the cost-sorted member order was used                */
 } simplyp_stats;
 
 typedef struct simplyp_ctx simplyp_ctx;
@@ -163,6 +167,8 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
  *   out               device  [n_cols][D][n_out_reaches][E] fp64, n_cols = popcount(out_mask),
  *                             columns in ascending SIMPLYP_OUT_* order
  *   member_status     device  [E] int32, OR of SIMPLYP_STATUS_* bits (zeroed by the call)
+ *   member_of_slot    device  [E] int32 or NULL: with opts.out_slot_order = 1, column j of `out` belongs to member
+ *                             member_of_slot[j] (required in that mode)
  *   member_rhs_evals  device  [E] uint32 or NULL: right-hand-side evaluations spent on each member, summed
  *                             over its reaches and days (what LSODA's infodict['nfe'] was to the reference's
  *                             caller; also the key the host sorts members by, see simplyp_amd/engine.py)
@@ -175,7 +181,8 @@ int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* 
                 const double* member_params, const double* reach_params,
                 const int32_t* up_ptr, const int32_t* up_idx,
                 const int32_t* out_reaches, int32_t n_out_reaches,
-                double* out, int32_t* member_status, uint32_t* member_rhs_evals, simplyp_stats* stats);
+                double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals,
+                simplyp_stats* stats);
 
 /*
  * simplyp_plan -- the routing schedule simplyp_run will use for a reach graph, without touching a
@@ -196,7 +203,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
                       const double* member_params, const double* reach_params,
                       const int32_t* up_ptr, const int32_t* up_idx,
                       const int32_t* out_reaches, int32_t n_out_reaches,
-                      double* out, int32_t* member_status, uint32_t* member_rhs_evals);
+                      double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals);
 int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats);
 
 /* Host-pinned staging buffers for callers that do not use torch (hipHostMalloc/hipHostFree). */

@@ -28,7 +28,7 @@ struct simplyp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_main = nullptr, ev_stop = nullptr;
     DeviceBuf route;          // [n_slots][4][D][E] fp64
     DeviceBuf sched;          // int32 schedule arrays
     DeviceBuf counters;       // 3 x uint64
@@ -225,6 +225,7 @@ int simplyp_ctx_create(int device, simplyp_ctx** out)
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (err == hipSuccess) { ctx->own_stream = true; err = hipEventCreate(&ctx->ev_start); }
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
+    if (err == hipSuccess) err = hipEventCreate(&ctx->ev_main);
     if (err == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -265,6 +266,7 @@ void simplyp_ctx_destroy(simplyp_ctx* ctx)
     if (ctx->balance.ptr) (void)hipFree(ctx->balance.ptr);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -310,13 +312,15 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
                       const double* member_params, const double* reach_params,
                       const int32_t* up_ptr, const int32_t* up_idx,
                       const int32_t* out_reaches, int32_t n_out_reaches,
-                      double* out, int32_t* member_status, uint32_t* member_rhs_evals)
+                      double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals)
 {
     int rc = check_args(ctx, dims, opts, forcing, member_params, reach_params, up_ptr, out, member_status,
                         out_reaches, n_out_reaches);
     if (rc != SIMPLYP_OK) return rc;
     if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is already pending on this context; call simplyp_sync");
     if (opts->dynamic_erod && !doy) return fail(ctx, SIMPLYP_ERR_ARG, "doy is required when dynamic_erod is set");
+    if (opts->out_slot_order && !member_of_slot)
+        return fail(ctx, SIMPLYP_ERR_ARG, "out_slot_order = 1 needs member_of_slot");
     const int E = dims->E, S = dims->S, D = dims->D;
     if (up_ptr[S] > 0 && !up_idx) return fail(ctx, SIMPLYP_ERR_ARG, "up_idx is NULL but up_ptr lists upstream reaches");
 
@@ -377,6 +381,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
 
     a.D_stride = D;
     a.perm = nullptr;
+    a.out_by_slot = 0;
     a.member_rhs = member_rhs_evals;
     const unsigned gx = (unsigned)((E + simplyp::WAVE - 1) / simplyp::WAVE);
     auto launch_all = [&](const simplyp::KernelArgs& base) -> int {
@@ -435,6 +440,18 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         a.perm = d_perm;
         ctx->balanced = 1;
     }
+    if (member_of_slot) {
+        if (ctx->balanced) {
+            HIP_TRY(ctx, hipMemcpyAsync(member_of_slot, a.perm, (size_t)E * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            std::vector<int32_t> ident((size_t)E);
+            std::iota(ident.begin(), ident.end(), 0);
+            HIP_TRY(ctx, hipMemcpyAsync(member_of_slot, ident.data(), (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    a.out_by_slot = opts->out_slot_order ? 1 : 0;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
     rc = launch_all(a);
     if (rc != SIMPLYP_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -454,11 +471,13 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
     if (stats) {
         unsigned long long c[3] = {0, 0, 0};
         HIP_TRY(ctx, hipMemcpy(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
-        float ms = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+        float ms = 0.f, ms_pilot = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_main, ctx->ev_stop));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms_pilot, ctx->ev_start, ctx->ev_main));
         memset(stats, 0, sizeof(*stats));
         stats->rhs_evals = c[0]; stats->steps = c[1]; stats->rejected = c[2];
         stats->kernel_ms = ms;
+        stats->pilot_ms = ctx->balanced ? ms_pilot : 0.0;
         stats->n_launches = ctx->n_launches;
         stats->balanced = ctx->balanced;
     }
@@ -470,10 +489,12 @@ int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* 
                 const double* member_params, const double* reach_params,
                 const int32_t* up_ptr, const int32_t* up_idx,
                 const int32_t* out_reaches, int32_t n_out_reaches,
-                double* out, int32_t* member_status, uint32_t* member_rhs_evals, simplyp_stats* stats)
+                double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals,
+                simplyp_stats* stats)
 {
     int rc = simplyp_run_async(ctx, dims, opts, forcing, doy, forcing_of_member, member_params, reach_params,
-                               up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status, member_rhs_evals);
+                               up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status, member_of_slot,
+                               member_rhs_evals);
     if (rc != SIMPLYP_OK) return rc;
     return simplyp_sync(ctx, stats);
 }

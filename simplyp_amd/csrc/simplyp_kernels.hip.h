@@ -32,6 +32,7 @@ struct KernelArgs {
     int E, S, D, n_sets;
     int D_stride;                   // row stride of `forcing` in days (D of the full run)
     const int* perm;                // [E] member handled by each lane slot, or nullptr = identity
+    int out_by_slot;                // 1: `out` columns are lane slots (coalesced), 0: member ids
     const double* forcing;          // [n_sets][2][D]
     const int* doy;                 // [D]
     const int* forcing_of_member;   // [E] or nullptr
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
                     }
                     if (oslot >= 0 && a.out_mask) {
                         const size_t col_stride = (size_t)D * a.n_out_reaches * E;
-                        double* o = a.out + ((size_t)d * a.n_out_reaches + oslot) * E + e;
+                        double* o = a.out + ((size_t)d * a.n_out_reaches + oslot) * E + (a.out_by_slot ? slot : e);
                         unsigned m = a.out_mask;
 #define PUT(col, val) if (m & (1u << (col))) { *o = (val); o += col_stride; }
                         PUT(SIMPLYP_OUT_VSA, y[0]) PUT(SIMPLYP_OUT_VSS, y[1]) PUT(SIMPLYP_OUT_VG, Vg_ode)

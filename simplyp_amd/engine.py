@@ -78,9 +78,9 @@ def lib():
     run_args = [vp, C.POINTER(abi.Dims), C.POINTER(abi.Opts), dp, i32p, i32p, dp, dp,
                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, dp, i32p]
     L.simplyp_run.restype = C.c_int
-    L.simplyp_run.argtypes = run_args + [vp, C.POINTER(abi.Stats)]
+    L.simplyp_run.argtypes = run_args + [vp, vp, C.POINTER(abi.Stats)]
     L.simplyp_run_async.restype = C.c_int
-    L.simplyp_run_async.argtypes = run_args + [vp]
+    L.simplyp_run_async.argtypes = run_args + [vp, vp]
     L.simplyp_sync.restype = C.c_int
     L.simplyp_sync.argtypes = [vp, C.POINTER(abi.Stats)]
     L.simplyp_plan.restype = C.c_int
@@ -170,13 +170,15 @@ class Engine(object):
         return t.to(self.tdev).contiguous()
 
     def run(self, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing_of_member=None,
-            out_reaches=None, out=None, member_rhs=None):
+            out_reaches=None, out=None, member_rhs=None, member_of_slot=None):
         """Integrate every (member, reach) through all days on the device.
 
         forcing [n_sets,2,D], doy [D], member_params [NP_M,E], reach_params [NP_R,S,E] may be numpy
         arrays or device tensors.  Returns (out [n_cols,D,n_out_reaches,E] device tensor,
         status [E] device tensor, stats dict).  ``member_rhs``: optional int32 device tensor [E] that
-        receives the per-member count of right-hand-side evaluations.
+        receives the per-member count of right-hand-side evaluations.  With ``opts.out_slot_order`` the
+        columns of ``out`` are lane slots; ``member_of_slot`` (int32 device tensor [E], allocated here when
+        not given and returned in stats['member_of_slot']) maps them back to members.
         """
         torch = self.torch
         L = lib()
@@ -206,6 +208,8 @@ class Engine(object):
             raise ValueError("out must be a contiguous float64 device tensor of shape %s" % ((ncols, D, n_or, E),))
         assert out.numel() * 8 == L.simplyp_out_bytes(C.byref(dims), C.byref(opts), n_or)
         status = torch.empty((E,), dtype=torch.int32, device=self.tdev)
+        if opts.out_slot_order and member_of_slot is None:
+            member_of_slot = torch.empty((E,), dtype=torch.int32, device=self.tdev)
         stats = abi.Stats()
         with torch.cuda.device(self.tdev):
             if self._use_torch_stream:
@@ -217,9 +221,13 @@ class Engine(object):
             rc = L.simplyp_run(self._h, C.byref(dims), C.byref(opts), f.data_ptr(), dy.data_ptr(),
                                None if fom is None else fom.data_ptr(), mp.data_ptr(), rp.data_ptr(),
                                ip(up_ptr), ip(up_idx), ip(oreach), n_or, out.data_ptr(), status.data_ptr(),
+                               None if member_of_slot is None else member_of_slot.data_ptr(),
                                None if member_rhs is None else member_rhs.data_ptr(), C.byref(stats))
         self._check(rc, 'simplyp_run')
-        return out, status, stats.as_dict()
+        sd = stats.as_dict()
+        if member_of_slot is not None:
+            sd['member_of_slot'] = member_of_slot
+        return out, status, sd
 
 
 _engines = {}

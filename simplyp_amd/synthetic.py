@@ -67,3 +67,60 @@ def c3_problem(n_members, st_dt='1981-01-01', end_dt='2010-12-31', seed=C3_SEED,
                          run_mode_cal=p_SU.run_mode == 'cal', sc_qr0=scs.index(int(p['SC_Qr0'])), out_mask=out_mask)
     return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx,
                 opts=opts, met=met_df)
+
+
+C4_SEED = 20240602
+
+
+def c4_problem(n_members, n_reaches=256, n_days=18262, seed=C4_SEED, solver=None, out_mask=marshal.MASK_REACH5,
+               out_reaches='last'):
+    """BASELINE config C4: a synthetic linear chain of `n_reaches` sub-catchments (reach i drains reach i-1),
+    4 land-use classes active (IG erodibility, newly-converted arable land on every 4th reach), Tarland forcing
+    tiled to `n_days` (1981-2010 then again from 1981), members drawn from the C3 distribution.
+
+    Per-reach parameters: A_catch log-uniform 5-50 km2, L_reach 2-15 km, slopes 1-12
+    degrees, land-use fractions Dirichlet(2,3,5) rounded to multiples of 1/1024 so that f_Ar + f_IG + f_S == 1
+    exactly in floating point, f_NC_Ar = 0.1 on every 4th reach."""
+    from . import abi
+    import pandas as pd
+    met_df, p_struc, p_SU, p_LU, p_SC, p, dyn = tarland_inputs('1981-01-01', '2010-12-31', dynamic_epc0='y',
+                                                               dynamic_erod='y')
+    rng = np.random.default_rng(seed)
+    S = int(n_reaches)
+    frac = np.round(rng.dirichlet([2.0, 3.0, 5.0], S) * 1024.0)
+    frac[:, 2] = 1024.0 - frac[:, 0] - frac[:, 1]
+    frac /= 1024.0
+    cols = {}
+    base = p_SC[1]
+    for s in range(S):
+        col = base.copy()
+        col['A_catch'] = float(np.exp(rng.uniform(np.log(5.0), np.log(50.0))))
+        col['L_reach'] = float(rng.uniform(2000.0, 15000.0))
+        col['S_Ar'], col['S_IG'], col['S_SN'] = (float(x) for x in rng.uniform(1.0, 12.0, 3))
+        col['S_reach'] = float(rng.uniform(0.3, 2.5))
+        col['f_Ar'], col['f_IG'], col['f_S'] = (float(x) for x in frac[s])
+        col['f_NC_Ar'] = 0.1 if s % 4 == 3 else 0.0
+        col['f_NC_IG'] = 0.0
+        col['f_NC_S'] = 0.0
+        col['TDPeff'] = float(rng.uniform(0.0, 0.3))
+        cols[s + 1] = col
+    p_SC = pd.DataFrame(cols)
+    p = p.copy()
+    p['SC_list'] = np.arange(1, S + 1)
+    p['SC_Qr0'] = float(S)
+    p_struc = pd.DataFrame({'Upstream_SCs': pd.Series([np.nan] + list(range(1, S)), index=range(1, S + 1), dtype=object),
+                            'In_final_flux?': pd.Series([0] * (S - 1) + [1], index=range(1, S + 1))})
+    marshal.prologue(p_SU, p_LU, p_SC, p)
+    up_ptr, up_idx, _ = marshal.topology(p_struc, p)
+    over = monte_carlo_overrides(p, p_LU, n_members, seed)
+    mp = marshal.member_params(p, p_LU, n_members, over)
+    rp = marshal.reach_params(p_SC, p, n_members)
+    forcing, doy = marshal.forcing_arrays(met_df)
+    reps = -(-int(n_days) // forcing.shape[2])
+    forcing = np.ascontiguousarray(np.tile(forcing, (1, 1, reps))[:, :, :n_days])
+    doy = np.ascontiguousarray(np.tile(doy, reps)[:n_days])
+    opts = abi.make_opts(solver, dynamic_epc0=True, dynamic_erod=True, run_mode_cal=True, sc_qr0=S - 1,
+                         out_mask=out_mask)
+    oreach = [S - 1] if out_reaches == 'last' else out_reaches
+    return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx,
+                opts=opts, out_reaches=oreach)

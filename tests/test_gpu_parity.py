@@ -320,3 +320,41 @@ def test_load_balanced_run_is_bitwise_identical(engine0, name):
     assert np.array_equal(sa, sb) and sa[5] & abi.STATUS_NONFINITE and (np.delete(sa, 5) == 0).all()
     assert bool(torch.equal(w0, w1)) and st_a['rhs_evals'] == st_b['rhs_evals'] == int(w0.sum())
     assert int(w0.max()) > 1.2 * int(w0[w0 > 0].min())       # the members really do differ in cost
+
+
+def test_c4_chain_of_256_reaches_in_kernel(engine0, oracle_lib):
+    """BASELINE config C4's shape at test size: a 256-reach linear chain walked inside the kernel by one thread
+    per member (one launch, two recycled routing slots), 4 land-use classes, dynamic erodibility, 70 members,
+    400 days; final reach's five outputs against the oracle."""
+    pr = synthetic.c4_problem(70, n_reaches=256, n_days=400)
+    pl = engine.plan(pr['up_ptr'], pr['up_idx'])
+    assert pl['n_launches'] == 1 and pl['n_slots'] == 2
+    out, status, stats = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'],
+                                     pr['up_ptr'], pr['up_idx'], pr['opts'], out_reaches=pr['out_reaches'])
+    got = out.cpu().numpy()
+    assert got.shape == (5, 400, 1, 70) and int(status.max()) == 0 and stats['n_launches'] == 1
+    pick = [0, 33, 69]
+    sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
+    ref, rstatus, _ = cpu_run(oracle_lib, sub, out_reaches=pr['out_reaches'], n_threads=3)
+    assert rstatus.max() == 0
+    assert helpers.max_rel_err(got[..., pick], ref, floor=FLOOR) < 1e-7
+    # flow accumulates down the chain: the outlet carries far more water per unit of its own area than a headwater
+    assert got[1].mean() > 5.0
+
+
+def test_slot_order_output_mode(engine0):
+    """opts.out_slot_order = 1: `out` columns are lane slots (coalesced stores); member_of_slot maps them back.
+    Same numbers as the member-order run, bit for bit."""
+    E = 200
+    m = helpers.marshal_scenario('tarland_2004_dynamic', E=E, solver=dict(balance=1, balance_pilot_days=30))
+    rng = np.random.default_rng(23)
+    m['member_params'][marshal.PM_NAMES.index('a_Q')] *= rng.uniform(0.5, 2.0, E)
+    a, sa, _ = gpu_run(engine0, m)
+    m['opts'].out_slot_order = 1
+    b, sb, st = gpu_run(engine0, m)
+    mos = st['member_of_slot'].cpu().numpy()
+    assert st['balanced'] == 1 and sorted(mos) == list(range(E)) and not np.array_equal(mos, np.arange(E))
+    assert np.array_equal(b, a[..., mos]) and np.array_equal(sa, sb)
+    m['opts'].balance = 0                                # no reordering: identity map
+    c, _, st = gpu_run(engine0, m)
+    assert np.array_equal(st['member_of_slot'].cpu().numpy(), np.arange(E)) and np.array_equal(c, a)
