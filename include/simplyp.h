@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 5
+#define SIMPLYP_ABI_VERSION 6
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -120,6 +120,12 @@ typedef struct {
                                 a scatter of 8-byte words: correct, but HBM sees ~4x the output bytes as partial-sector
                                 writes).  1: `out` is written in lane-slot order, fully coalesced, and the caller gets
                                 the member id of every slot in `member_of_slot` (identity when no reordering happened) */
+    int32_t  time_chunk_days;/* single-reach ensembles, adaptive integrators: run as (time chunk x 64-member group) tasks
+                                pulled by one persistent wave per SIMD, so every SIMD stays busy whatever the members'
+                                relative costs.  0 = auto (chunks of 256 days when the ensemble needs more waves than
+                                the chip holds), > 0 = always, with this chunk length (rounded up to 256), < 0 = never.
+                                Results are unchanged bit for bit.                                              */
+    int32_t  reserved1;
 } simplyp_opts;
 
 typedef struct {
@@ -130,6 +136,8 @@ typedef struct {
     double   pilot_ms;       /* load balancing: pilot launches + host sort of the cost keys (0 when off)      */
     int32_t  n_launches;     /* kernel launches issued (one per routing stage)             */
     int32_t  balanced;       /* 1 when the cost-sorted member order was used                */
+    int32_t  queued;         /* 1 when the time-chunk task queue kernel ran                  */
+    int32_t  reserved;
 } simplyp_stats;
 
 typedef struct simplyp_ctx simplyp_ctx;

@@ -33,6 +33,8 @@ struct simplyp_ctx {
     DeviceBuf sched;          // int32 schedule arrays
     DeviceBuf counters;       // 3 x uint64
     DeviceBuf balance;        // [E] uint32 pilot counts + [E] int32 permutation
+    DeviceBuf queue;          // ticket, error, done[n_groups] (uint32) | ckpt[CKPT_N][E] (double)
+    int queued = 0;           // last run used the task-queue kernel
     int n_simd_slots = 1024;  // CUs x 4 SIMDs: wave slots at one resident wave per SIMD
     int balanced = 0;         // last run used the cost-sorted member order
     int n_launches = 0;
@@ -264,6 +266,7 @@ void simplyp_ctx_destroy(simplyp_ctx* ctx)
     if (ctx->sched.ptr) (void)hipFree(ctx->sched.ptr);
     if (ctx->counters.ptr) (void)hipFree(ctx->counters.ptr);
     if (ctx->balance.ptr) (void)hipFree(ctx->balance.ptr);
+    if (ctx->queue.ptr) (void)hipFree(ctx->queue.ptr);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
@@ -451,9 +454,41 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         }
     }
     a.out_by_slot = opts->out_slot_order ? 1 : 0;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
-    rc = launch_all(a);
-    if (rc != SIMPLYP_OK) return rc;
+
+    // ---- task-queue kernel: single-reach ensembles that need more waves than the chip holds at once ----
+    int chunk_days = opts->time_chunk_days > 0 ? opts->time_chunk_days : 256;
+    chunk_days = ((chunk_days + simplyp::TILE_D - 1) / simplyp::TILE_D) * simplyp::TILE_D;
+    const bool want_queue = S == 1 && opts->integrator != SIMPLYP_INTEG_RK4 && D > chunk_days &&
+        (opts->time_chunk_days > 0 || (opts->time_chunk_days == 0 && (int)gx > ctx->n_simd_slots));
+    ctx->queued = 0;
+    if (want_queue) {
+        const int n_groups = (int)gx, n_chunks = (D + chunk_days - 1) / chunk_days;
+        const size_t flags_bytes = (((size_t)n_groups + 2) * sizeof(unsigned) + 255) / 256 * 256;
+        rc = ensure(ctx, ctx->queue, flags_bytes + (size_t)simplyp::CKPT_N * E * sizeof(double));
+        if (rc != SIMPLYP_OK) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->queue.ptr, 0, flags_bytes, ctx->stream));
+        simplyp::QueueArgs q;
+        unsigned* flags = (unsigned*)ctx->queue.ptr;
+        q.ticket = flags; q.error = flags + 1; q.done = flags + 2;
+        q.ckpt = (double*)((char*)ctx->queue.ptr + flags_bytes);
+        q.n_groups = n_groups; q.n_chunks = n_chunks; q.chunk_days = chunk_days;
+        q.max_polls = 20000000u;          // x (s_sleep 64 ~ 2 us): a wait longer than ~40 s means something is broken
+        simplyp::KernelArgs k = a;
+        k.chain_ptr = dsched + off_cptr[0];
+        k.chain_reach = dsched + off_creach[0];
+        const unsigned workers = (unsigned)std::min(n_groups, ctx->n_simd_slots);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+        if (opts->integrator == SIMPLYP_INTEG_CASHKARP)
+            hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
+        else
+            hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->queued = 1;
+    } else {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+        rc = launch_all(a);
+        if (rc != SIMPLYP_OK) return rc;
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->n_launches = (int)sch.launches.size();
     ctx->pending = true;
@@ -468,6 +503,11 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->queued) {
+        unsigned err = 0;
+        HIP_TRY(ctx, hipMemcpy(&err, (unsigned*)ctx->queue.ptr + 1, sizeof(err), hipMemcpyDeviceToHost));
+        if (err) return fail(ctx, SIMPLYP_ERR_DEVICE, "task-queue kernel: a wave timed out waiting for a time chunk; results are incomplete");
+    }
     if (stats) {
         unsigned long long c[3] = {0, 0, 0};
         HIP_TRY(ctx, hipMemcpy(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
@@ -480,6 +520,7 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->pilot_ms = ctx->balanced ? ms_pilot : 0.0;
         stats->n_launches = ctx->n_launches;
         stats->balanced = ctx->balanced;
+        stats->queued = ctx->queued;
     }
     return SIMPLYP_OK;
 }

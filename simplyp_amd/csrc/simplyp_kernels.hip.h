@@ -487,15 +487,16 @@ __device__ __forceinline__ void soil_p_update(double P_netInput, double A_catch,
     Plab = (0.0 > Pl) ? 0.0 : Pl;                                                 // :697
 }
 
-template <int INTEG>
-__global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
-{
-    __shared__ double s_P[TILE_D];
-    __shared__ double s_E[TILE_D];
-    __shared__ int s_doy[TILE_D];
+// Everything one lane does for one member over days [d_begin, d_end) of every reach of its chain.
+// `ckpt` ([CKPT_N][E], slot-major) carries a member's state across a time-chunk boundary for the queue
+// kernel (single-reach problems); the chain kernel passes nullptr and runs all days of every reach.
+constexpr int CKPT_N = 15;    // y[8], Plab_A, TDPs_A, Plab_NC, TDPs_NC, conc_A, conc_NC, h_carry
 
-    const int lane = threadIdx.x;
-    const int slot_raw = blockIdx.x * WAVE + lane;
+template <int INTEG>
+__device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, double* s_E, int* s_doy,
+                                         const int lane, const int slot_raw, const int chain,
+                                         const int d_begin, const int d_end, double* ckpt)
+{
     const bool active = slot_raw < a.E;
     const int slot = active ? slot_raw : a.E - 1;     // inactive lanes shadow the last slot, store nothing
     // Load balancing (host side, simplyp_hip.hip): lane slots may be handed members in order of expected
@@ -530,7 +531,6 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
     unsigned n_rhs = 0, n_steps = 0, n_rej = 0;
     int stat = 0;
 
-    const int chain = blockIdx.y;
     for (int ci = a.chain_ptr[chain]; ci < a.chain_ptr[chain + 1]; ++ci) {
         const int s = a.chain_reach[ci];
 
@@ -568,6 +568,13 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
         double conc_A = TDPs_A / fc;                                                              // :438
         double conc_NC = TDPs_NC / fc;                                                            // :446 (VsA0 == VsS0)
         double h_carry = a.step_len / (double)(a.substeps > 0 ? a.substeps : 1);
+        if (ckpt && d_begin > 0) {      // resume from the previous time chunk (written by whichever wave ran it)
+            const double* k = ckpt + slot;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = k[(size_t)i * E];
+            Plab_A = k[(size_t)8 * E]; TDPs_A = k[(size_t)9 * E]; Plab_NC = k[(size_t)10 * E]; TDPs_NC = k[(size_t)11 * E];
+            conc_A = k[(size_t)12 * E]; conc_NC = k[(size_t)13 * E]; h_carry = k[(size_t)14 * E];
+        }
 
         // per-reach pieces of the day constants
         DayConst c;
@@ -601,8 +608,8 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
         const int oslot = a.out_slot[s];
         double* route_w = rslot >= 0 ? a.route + (size_t)rslot * 4 * D * E : nullptr;
 
-        for (int d0 = 0; d0 < D; d0 += TILE_D) {
-            const int nd = min(TILE_D, D - d0);
+        for (int d0 = d_begin; d0 < d_end; d0 += TILE_D) {
+            const int nd = min(TILE_D, d_end - d0);
             if (shared_forcing) {
                 __syncthreads();
                 for (int i = lane; i < nd; i += WAVE) { s_P[i] = Pser[d0 + i]; s_E[i] = Eser[d0 + i]; }
@@ -761,6 +768,13 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
                 }
             }
         }
+        if (ckpt && d_end < D && active) {      // hand the state to whichever wave runs the next time chunk
+            double* k = ckpt + slot;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) k[(size_t)i * E] = y[i];
+            k[(size_t)8 * E] = Plab_A; k[(size_t)9 * E] = TDPs_A; k[(size_t)10 * E] = Plab_NC; k[(size_t)11 * E] = TDPs_NC;
+            k[(size_t)12 * E] = conc_A; k[(size_t)13 * E] = conc_NC; k[(size_t)14 * E] = h_carry;
+        }
     }
 #undef MPv
 #undef RPv
@@ -775,7 +789,82 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
         atomicAdd(&a.counters[0], v0); atomicAdd(&a.counters[1], v1); atomicAdd(&a.counters[2], v2);
     }
     if (active && stat) atomicOr(&a.status[e], stat);
-    if (active && a.member_rhs) atomicAdd(&a.member_rhs[e], n_rhs);      // several chains may share a member
+    if (active && a.member_rhs) atomicAdd(&a.member_rhs[e], n_rhs);      // several chains / time chunks per member
+}
+
+template <int INTEG>
+__global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
+{
+    __shared__ double s_P[TILE_D];
+    __shared__ double s_E[TILE_D];
+    __shared__ int s_doy[TILE_D];
+    run_slot<INTEG>(a, s_P, s_E, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, blockIdx.y, 0, a.D, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------
+// Work-conserving variant for single-reach ensembles that need more waves than the chip holds.
+//
+// The run is cut into tasks (time chunk c, member group g of 64 lane slots), numbered chunk-major.
+// One persistent wave per SIMD pulls task numbers from a ticket counter; task (c, g) needs the state task
+// (c-1, g) left in `ckpt`, which some other wave may still be computing, so the worker waits on
+// done[g] >= c.  Tickets are handed out in task order, so the task waited for always holds a smaller
+// ticket: it is running on a resident wave (or finished) and itself waits only on still smaller tickets --
+// no assumption about dispatch order or placement, no deadlock.  Every SIMD stays busy until the ticket
+// counter runs out, whatever the members' relative costs.
+//
+// Hand-off (MI355X_MICROARCH.md, "Valid forms"): producer = plain stores, s_waitcnt vmcnt(0), agent-scope
+// release, s_waitcnt vmcnt(0) (asm, so the compiler cannot drop it), relaxed agent-scope flag store;
+// consumer = relaxed agent-scope poll by one lane (with s_sleep), agent-scope acquire, s_waitcnt vmcnt(0),
+// then plain loads.  The spin is bounded: on timeout the wave raises q.error and every worker drains.
+struct QueueArgs {
+    unsigned* ticket;          // next task number
+    unsigned* done;            // [n_groups] chunks completed per member group
+    unsigned* error;           // set to 1 on a wait timeout
+    double* ckpt;              // [CKPT_N][E]
+    int n_groups, n_chunks, chunk_days;
+    unsigned max_polls;
+};
+
+template <int INTEG>
+__global__ __launch_bounds__(WAVE) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
+{
+    __shared__ double s_P[TILE_D];
+    __shared__ double s_E[TILE_D];
+    __shared__ int s_doy[TILE_D];
+    const int lane = threadIdx.x;
+    const unsigned n_tasks = (unsigned)q.n_groups * (unsigned)q.n_chunks;
+    for (;;) {
+        unsigned k = 0;
+        if (lane == 0) k = atomicAdd(q.ticket, 1u);
+        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+        if (k >= n_tasks) break;
+        const int c = (int)(k / (unsigned)q.n_groups), g = (int)(k % (unsigned)q.n_groups);
+        if (c > 0) {
+            int ok = 1;
+            if (lane == 0) {
+                unsigned polls = 0;
+                while (__hip_atomic_load(&q.done[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c) {
+                    __builtin_amdgcn_s_sleep(64);
+                    if (++polls > q.max_polls ||
+                        __hip_atomic_load(q.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+                }
+            }
+            ok = __builtin_amdgcn_readfirstlane(ok);
+            if (!ok) {
+                if (lane == 0) __hip_atomic_store(q.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const int d_begin = c * q.chunk_days;
+        const int d_end = min(a.D, d_begin + q.chunk_days);
+        run_slot<INTEG>(a, s_P, s_E, s_doy, lane, g * WAVE + lane, 0, d_begin, d_end, q.ckpt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&q.done[g], (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace simplyp

@@ -358,3 +358,39 @@ def test_slot_order_output_mode(engine0):
     m['opts'].balance = 0                                # no reordering: identity map
     c, _, st = gpu_run(engine0, m)
     assert np.array_equal(st['member_of_slot'].cpu().numpy(), np.arange(E)) and np.array_equal(c, a)
+
+
+@pytest.mark.parametrize('integrator', ['cashkarp_aug', 'cashkarp'])
+def test_task_queue_kernel_is_bitwise_identical(engine0, integrator):
+    """opts.time_chunk_days > 0: the run is cut into (time chunk x 64-member group) tasks pulled by persistent
+    waves, state handed over through memory between chunks.  Same results bit for bit, with and without the
+    cost-sorted member order, in member order and in slot order."""
+    import torch
+    E = 300                                         # 5 groups, the last one ragged (44 lanes)
+    name = 'tarland_1981_2010_dynamic'
+    base = helpers.marshal_scenario(name, E=E, out_mask=marshal.MASK_REACH5, solver=dict(integrator=integrator, balance=0, time_chunk_days=-1))
+    D = 2200                                        # 9 chunks of 256 days (the last one short)
+    base['forcing'] = np.ascontiguousarray(base['forcing'][:, :, :D])
+    base['doy'] = np.ascontiguousarray(base['doy'][:D])
+    rng = np.random.default_rng(29)
+    for pname, lo, hi in (('a_Q', 0.5, 2.0), ('T_s_A', 0.5, 2.0), ('fc', 0.8, 1.2)):
+        base['member_params'][marshal.PM_NAMES.index(pname)] *= rng.uniform(lo, hi, E)
+    base['member_params'][marshal.PM_NAMES.index('T_s_S'), 77] = np.nan       # a poisoned member rides along
+    w0 = torch.zeros(E, dtype=torch.int32, device='cuda')
+    ref, sref, st0 = gpu_run(engine0, base, member_rhs=w0)
+    assert st0['queued'] == 0
+    for balance, slot_order in ((0, 0), (1, 0), (1, 1)):
+        m = dict(base)
+        m['opts'] = abi.make_opts(dict(integrator=integrator, balance=balance, balance_pilot_days=100, time_chunk_days=256,
+                                       out_slot_order=slot_order), dynamic_epc0=True, dynamic_erod=True,
+                                  out_mask=marshal.MASK_REACH5)
+        w1 = torch.zeros(E, dtype=torch.int32, device='cuda')
+        got, sgot, st = gpu_run(engine0, m, member_rhs=w1)
+        assert st['queued'] == 1 and st['balanced'] == balance
+        if slot_order:
+            got_m = np.empty_like(got)
+            got_m[..., st['member_of_slot'].cpu().numpy()] = got
+            got = got_m
+        assert np.array_equal(got, ref, equal_nan=True), (balance, slot_order)
+        assert np.array_equal(sgot, sref) and sref[77] & abi.STATUS_NONFINITE
+        assert bool(torch.equal(w0, w1)) and st['rhs_evals'] == st0['rhs_evals']
