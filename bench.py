@@ -121,11 +121,12 @@ def main():
                                       "per-member summaries" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "simplyp_chain_kernel<%d>" % prob['opts'].integrator, "kernel_ms": k_ms,
+                         "kernel": "simplyp_%s_kernel<%d>" % ("queue" if stats.get('queued') else "chain", prob['opts'].integrator),
+                         "kernel_ms": k_ms,
                          "pilot_ms": stats.get('pilot_ms', 0.0),
                          "algorithmic_bytes_per_launch": BYTES_PER_CD_REACH5 * float(E) * D,
                          "note": "the path is fp64-VALU-bound, not HBM-bound: see fp64_valu"},
-            "fp64_valu": {"rhs_evals_per_catchment_day": rhs_per_cd,
+            "fp64_valu": {"rhs_evals_per_catchment_day": rhs_per_cd, "simt_efficiency": stats.get('simt_efficiency'),
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS},
             "members_flagged": n_bad,
             "parity": None if args.no_parity else parity_check(eng, prob['opts']),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 6
+#define SIMPLYP_ABI_VERSION 7
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -134,6 +134,8 @@ typedef struct {
     uint64_t rejected;       /* rejected steps (Cash-Karp)                                 */
     double   kernel_ms;      /* device time of the main launches of this run (HIP events on the run's stream) */
     double   pilot_ms;       /* load balancing: pilot launches + host sort of the cost keys (0 when off)      */
+    double   simt_efficiency;/* adaptive integrators: lanes that needed the attempt / lanes that executed it (1 = no
+                                divergence between the members of a wavefront)                                  */
     int32_t  n_launches;     /* kernel launches issued (one per routing stage)             */
     int32_t  balanced;       /* 1 when the cost-sorted member order was used                */
     int32_t  queued;         /* 1 when the time-chunk task queue kernel ran                  */

@@ -31,8 +31,9 @@ struct simplyp_ctx {
     hipEvent_t ev_start = nullptr, ev_main = nullptr, ev_stop = nullptr;
     DeviceBuf route;          // [n_slots][4][D][E] fp64
     DeviceBuf sched;          // int32 schedule arrays
-    DeviceBuf counters;       // 3 x uint64
+    DeviceBuf counters;       // 4 x uint64
     DeviceBuf balance;        // [E] uint32 pilot counts + [E] int32 permutation
+    DeviceBuf sorted_params;  // slot-ordered copies of member_params, reach_params, forcing_of_member
     DeviceBuf queue;          // ticket, error, done[n_groups] (uint32) | ckpt[CKPT_N][E] (double)
     int queued = 0;           // last run used the task-queue kernel
     int n_simd_slots = 1024;  // CUs x 4 SIMDs: wave slots at one resident wave per SIMD
@@ -266,6 +267,7 @@ void simplyp_ctx_destroy(simplyp_ctx* ctx)
     if (ctx->sched.ptr) (void)hipFree(ctx->sched.ptr);
     if (ctx->counters.ptr) (void)hipFree(ctx->counters.ptr);
     if (ctx->balance.ptr) (void)hipFree(ctx->balance.ptr);
+    if (ctx->sorted_params.ptr) (void)hipFree(ctx->sorted_params.ptr);
     if (ctx->queue.ptr) (void)hipFree(ctx->queue.ptr);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -339,7 +341,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         rc = ensure(ctx, ctx->route, slot_bytes * sch.n_slots);
         if (rc != SIMPLYP_OK) return rc;
     }
-    rc = ensure(ctx, ctx->counters, 3 * sizeof(unsigned long long));
+    rc = ensure(ctx, ctx->counters, 4 * sizeof(unsigned long long));
     if (rc != SIMPLYP_OK) return rc;
 
     // int32 schedule block: up_ptr | up_idx | route_slot | out_slot | per launch: chain_ptr | chain_reach
@@ -361,7 +363,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     // pageable source: the copy is staged before hipMemcpyAsync returns, `host` may go out of scope
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sched.ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 4 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(member_status, 0, (size_t)E * sizeof(int32_t), ctx->stream));
     if (member_rhs_evals) HIP_TRY(ctx, hipMemsetAsync(member_rhs_evals, 0, (size_t)E * sizeof(uint32_t), ctx->stream));
 
@@ -385,6 +387,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     a.D_stride = D;
     a.perm = nullptr;
     a.out_by_slot = 0;
+    a.params_by_slot = 0;
     a.member_rhs = member_rhs_evals;
     const unsigned gx = (unsigned)((E + simplyp::WAVE - 1) / simplyp::WAVE);
     auto launch_all = [&](const simplyp::KernelArgs& base) -> int {
@@ -438,10 +441,27 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         HIP_TRY(ctx, hipMemcpyAsync(d_perm, perm.data(), (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // the pilot's bookkeeping must not leak into the real run
-        HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 4 * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(member_status, 0, (size_t)E * sizeof(int32_t), ctx->stream));
         a.perm = d_perm;
         ctx->balanced = 1;
+        // slot-ordered copies of the parameter tables: the main kernels then read them coalesced
+        const size_t n_mp = (size_t)SIMPLYP_NP_M * E, n_rp = (size_t)SIMPLYP_NP_R * S * E;
+        const size_t bytes = (n_mp + n_rp) * sizeof(double) + (forcing_of_member ? (size_t)E * sizeof(int32_t) : 0);
+        rc = ensure(ctx, ctx->sorted_params, bytes);
+        if (rc != SIMPLYP_OK) return rc;
+        double* s_mp = (double*)ctx->sorted_params.ptr;
+        double* s_rp = s_mp + n_mp;
+        int32_t* s_fom = (int32_t*)(s_rp + n_rp);
+        const dim3 gb(256), gg((unsigned)((E + 255) / 256), 16);
+        hipLaunchKernelGGL(simplyp::gather_columns_kernel<double>, gg, gb, 0, ctx->stream, member_params, s_mp, d_perm, (int)SIMPLYP_NP_M, E);
+        hipLaunchKernelGGL(simplyp::gather_columns_kernel<double>, gg, gb, 0, ctx->stream, reach_params, s_rp, d_perm, (int)SIMPLYP_NP_R * S, E);
+        if (forcing_of_member)
+            hipLaunchKernelGGL(simplyp::gather_columns_kernel<int32_t>, dim3(gg.x, 1), gb, 0, ctx->stream, forcing_of_member, s_fom, d_perm, 1, E);
+        HIP_TRY(ctx, hipGetLastError());
+        a.mp = s_mp; a.rp = s_rp;
+        if (forcing_of_member) a.forcing_of_member = s_fom;
+        a.params_by_slot = 1;
     }
     if (member_of_slot) {
         if (ctx->balanced) {
@@ -509,7 +529,7 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         if (err) return fail(ctx, SIMPLYP_ERR_DEVICE, "task-queue kernel: a wave timed out waiting for a time chunk; results are incomplete");
     }
     if (stats) {
-        unsigned long long c[3] = {0, 0, 0};
+        unsigned long long c[4] = {0, 0, 0, 0};
         HIP_TRY(ctx, hipMemcpy(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
         float ms = 0.f, ms_pilot = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_main, ctx->ev_stop));
@@ -517,6 +537,8 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         memset(stats, 0, sizeof(*stats));
         stats->rhs_evals = c[0]; stats->steps = c[1]; stats->rejected = c[2];
         stats->kernel_ms = ms;
+        // lanes doing useful work per issued attempt: (attempts summed over lanes) / (64 x wave-level attempts)
+        stats->simt_efficiency = c[3] ? (double)(c[0] / 6) / (64.0 * (double)c[3]) : 1.0;
         stats->pilot_ms = ctx->balanced ? ms_pilot : 0.0;
         stats->n_launches = ctx->n_launches;
         stats->balanced = ctx->balanced;

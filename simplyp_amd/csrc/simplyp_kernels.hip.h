@@ -33,6 +33,7 @@ struct KernelArgs {
     int D_stride;                   // row stride of `forcing` in days (D of the full run)
     const int* perm;                // [E] member handled by each lane slot, or nullptr = identity
     int out_by_slot;                // 1: `out` columns are lane slots (coalesced), 0: member ids
+    int params_by_slot;             // 1: mp / rp / forcing_of_member were gathered into slot order by the host side
     const double* forcing;          // [n_sets][2][D]
     const int* doy;                 // [D]
     const int* forcing_of_member;   // [E] or nullptr
@@ -41,7 +42,7 @@ struct KernelArgs {
     double* out;                    // [ncols][D][n_out_reaches][E]
     int* status;                    // [E]
     unsigned* member_rhs;           // [E] or nullptr: rhs evaluations per member
-    unsigned long long* counters;   // rhs, steps, rejected
+    unsigned long long* counters;   // rhs, steps, rejected, wave-level attempts
     double* route;                  // [n_slots][4][D][E] daily series handed downstream
     const int* chain_ptr;           // [n_chains+1]   (this launch)
     const int* chain_reach;         // reach ids in processing order
@@ -305,7 +306,7 @@ struct SysAug {
 // Cash-Karp 5(4), per-lane step control; the rule is documented (and mirrored for the parity
 // tests) in oracle/simplyp_oracle.c `cashkarp_day` / `cashkarp_aug_day`.  Lanes that have reached T idle
 // with a zero step until the slowest lane of the wavefront is done.
-struct CkCounters { unsigned rhs, steps, rejected; bool capped, poisoned; };
+struct CkCounters { unsigned rhs, steps, rejected, wave_trips; bool capped, poisoned; };
 
 template <class SYS>
 __device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], const DayConst& c, double T,
@@ -335,6 +336,7 @@ __device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], co
     }
 
     while (__any(alive)) {
+        ++cnt.wave_trips;                 // one attempt issued for the whole wavefront, whoever still needs it
         const double rem = T - t;
         double hh = h;
         if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
@@ -507,10 +509,11 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
     const int S = a.S, D = a.D;
     const size_t Dst = (size_t)a.D_stride;            // days per forcing row (>= D: the pilot run uses fewer days)
 
-#define MPv(idx) (a.mp[(size_t)(idx) * E + e])
-#define RPv(idx, s) (a.rp[((size_t)(idx) * S + (s)) * E + e])
+    const int pe = a.params_by_slot ? slot : e;       // column of the parameter arrays
+#define MPv(idx) (a.mp[(size_t)(idx) * E + pe])
+#define RPv(idx, s) (a.rp[((size_t)(idx) * S + (s)) * E + pe])
 
-    const int set = a.forcing_of_member ? a.forcing_of_member[e] : 0;
+    const int set = a.forcing_of_member ? a.forcing_of_member[pe] : 0;
     const bool shared_forcing = (a.forcing_of_member == nullptr);
     const double* Pser = a.forcing + (size_t)set * 2 * Dst;
     const double* Eser = Pser + Dst;
@@ -528,7 +531,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                                    + RPv(SIMPLYP_PR_F_NC_IG, S - 1) * RPv(SIMPLYP_PR_F_IG, S - 1),
                                    RPv(SIMPLYP_PR_F_NC_S, S - 1));
 
-    unsigned n_rhs = 0, n_steps = 0, n_rej = 0;
+    unsigned n_rhs = 0, n_steps = 0, n_rej = 0, n_trips = 0;
     int stat = 0;
 
     for (int ci = a.chain_ptr[chain]; ci < a.chain_ptr[chain + 1]; ++ci) {
@@ -693,9 +696,9 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     n_rhs += 4u * (unsigned)a.substeps; n_steps += (unsigned)a.substeps;
                     if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));    // Vr = Kv Qr^(1-b_Q), see oracle
                 } else if (INTEG == SIMPLYP_INTEG_CASHKARP) {
-                    CkCounters cnt = {0u, 0u, 0u, false, false};
+                    CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
                     ck_day<SysLiteral>(y, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
-                    n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected;
+                    n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
                     if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));
@@ -706,9 +709,9 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     sp_exp2(-mu * y[0], -mu * y[1], z[7], z[8]);
                     const double lq0 = sp_log(y[4]);
                     sp_exp2(b_Q * lq0, k_M * lq0, z[9], z[10]);
-                    CkCounters cnt = {0u, 0u, 0u, false, false};
+                    CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
                     ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
-                    n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected;
+                    n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
                     y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
@@ -787,6 +790,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
     }
     if (lane == 0) {
         atomicAdd(&a.counters[0], v0); atomicAdd(&a.counters[1], v1); atomicAdd(&a.counters[2], v2);
+        atomicAdd(&a.counters[3], (unsigned long long)n_trips);      // wave-level attempts (lane 0's count = the wave's)
     }
     if (active && stat) atomicOr(&a.status[e], stat);
     if (active && a.member_rhs) atomicAdd(&a.member_rhs[e], n_rhs);      // several chains / time chunks per member
@@ -865,6 +869,18 @@ __global__ __launch_bounds__(WAVE) void simplyp_queue_kernel(const KernelArgs a,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&q.done[g], (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// Gather the columns of a [rows][E] array into lane-slot order: dst[r][i] = src[r][perm[i]].  One pass over the
+// parameter tables (tens of MB) so that the time-stepping kernels read them coalesced, however often.
+template <typename T>
+__global__ void gather_columns_kernel(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ perm,
+                                      int rows, int E)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const int e = perm[i];
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) dst[(size_t)r * E + i] = src[(size_t)r * E + e];
 }
 
 }  // namespace simplyp

@@ -17,7 +17,7 @@ for E in [int(x) for x in sys.argv[1:]] or [65536, 100000]:
             for rep in range(2):
                 o, st, stats = eng.run(f, doy, mp_, rp_, pr['up_ptr'], pr['up_idx'], pr['opts'], out=out)
             n = E * D
-            print('E=%d %-12s %-20s kernel %8.1f ms  rhs/cd %.1f -> %.3e cd/s' % (E, 'replicated' if replicated else 'monte-carlo', tag, stats['kernel_ms'], stats['rhs_evals'] / n, n / stats['kernel_ms'] * 1e3), flush=True)
+            print('E=%d %-12s %-20s kernel %8.1f ms pilot %5.1f rhs/cd %.1f simt_eff %.3f queued %d -> %.3e cd/s' % (E, 'replicated' if replicated else 'monte-carlo', tag, stats['kernel_ms'], stats['pilot_ms'], stats['rhs_evals'] / n, stats['simt_efficiency'], stats['queued'], n / stats['kernel_ms'] * 1e3), flush=True)
         run(mp, rp, 'as drawn')
         if not replicated:
             Dp = 256
