@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 7
+#define SIMPLYP_ABI_VERSION 8
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -125,7 +125,8 @@ typedef struct {
                                 relative costs.  0 = auto (chunks of 256 days when the ensemble needs more waves than
                                 the chip holds), > 0 = always, with this chunk length (rounded up to 256), < 0 = never.
                                 Results are unchanged bit for bit.                                              */
-    int32_t  reserved1;
+    int32_t  n_periods;      /* time-reduced output: 0 = one output row per day; > 0 = `out` has n_periods rows per column,
+                                row p = sum over the days d with period_of_day[d] == p (e.g. calendar years) */
 } simplyp_opts;
 
 typedef struct {
@@ -157,7 +158,7 @@ const char* simplyp_last_error(const simplyp_ctx* ctx);   /* ctx may be NULL: cr
  * .cuda_stream) so the launches order with the caller's own copies; NULL = a private stream. */
 int  simplyp_ctx_set_stream(simplyp_ctx* ctx, void* hip_stream);
 
-/* Bytes of `out` that simplyp_run will write: popcount(out_mask) * D * n_out_reaches * E * 8. */
+/* Bytes of `out` that simplyp_run will write: popcount(out_mask) * (n_periods ? n_periods : D) * n_out_reaches * E * 8. */
 int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, int32_t n_out_reaches);
 
 /*
@@ -167,6 +168,7 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
  *   forcing           device  [n_forcing_sets][2][D]   row 0 = P (met_df['P'], model.py:497),
  *                                                      row 1 = PET (model.py:498)
  *   doy               device  [D]        day of year 1..366 (met_df.index[idx].dayofyear, :550)
+ *   period_of_day     device  [D] int32 in [0, opts.n_periods), or NULL when opts.n_periods == 0
  *   forcing_of_member device  [E] or NULL (all members use set 0)
  *   member_params     device  [SIMPLYP_NP_M][E]
  *   reach_params      device  [SIMPLYP_NP_R][S][E]
@@ -174,7 +176,7 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
  *                             model.py:480-487), zero-based, up_idx[k] < own id, shared by all
  *                             members; up_ptr has S+1 entries
  *   out_reaches       host    [n_out_reaches] reaches whose columns are written, or NULL = all S
- *   out               device  [n_cols][D][n_out_reaches][E] fp64, n_cols = popcount(out_mask),
+ *   out               device  [n_cols][D or n_periods][n_out_reaches][E] fp64, n_cols = popcount(out_mask),
  *                             columns in ascending SIMPLYP_OUT_* order
  *   member_status     device  [E] int32, OR of SIMPLYP_STATUS_* bits (zeroed by the call)
  *   member_of_slot    device  [E] int32 or NULL: with opts.out_slot_order = 1, column j of `out` belongs to member
@@ -187,7 +189,8 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
  * The call is synchronous: it returns after the last kernel has finished.
  */
 int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
-                const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                const double* forcing, const int32_t* doy, const int32_t* period_of_day,
+                const int32_t* forcing_of_member,
                 const double* member_params, const double* reach_params,
                 const int32_t* up_ptr, const int32_t* up_idx,
                 const int32_t* out_reaches, int32_t n_out_reaches,
@@ -209,7 +212,8 @@ int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx,
 /* Same as simplyp_run but only enqueues on the context's stream (for overlap with the
  * caller's own copies); simplyp_sync() waits and fills `stats`. */
 int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
-                      const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                      const double* forcing, const int32_t* doy, const int32_t* period_of_day,
+                      const int32_t* forcing_of_member,
                       const double* member_params, const double* reach_params,
                       const int32_t* up_ptr, const int32_t* up_idx,
                       const int32_t* out_reaches, int32_t n_out_reaches,

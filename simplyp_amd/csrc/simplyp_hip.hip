@@ -285,7 +285,8 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
 {
     if (!dims || !opts) return 0;
     const int64_t nor = n_out_reaches > 0 ? n_out_reaches : dims->S;
-    return (int64_t)popcount32(opts->out_mask & SIMPLYP_MASK_ALL) * dims->D * nor * dims->E * (int64_t)sizeof(double);
+    const int64_t rows = opts->n_periods > 0 ? opts->n_periods : dims->D;
+    return (int64_t)popcount32(opts->out_mask & SIMPLYP_MASK_ALL) * rows * nor * dims->E * (int64_t)sizeof(double);
 }
 
 int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_t* n_launches, int32_t* n_slots,
@@ -313,7 +314,8 @@ int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_
 }
 
 int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
-                      const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                      const double* forcing, const int32_t* doy, const int32_t* period_of_day,
+                      const int32_t* forcing_of_member,
                       const double* member_params, const double* reach_params,
                       const int32_t* up_ptr, const int32_t* up_idx,
                       const int32_t* out_reaches, int32_t n_out_reaches,
@@ -324,6 +326,8 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     if (rc != SIMPLYP_OK) return rc;
     if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is already pending on this context; call simplyp_sync");
     if (opts->dynamic_erod && !doy) return fail(ctx, SIMPLYP_ERR_ARG, "doy is required when dynamic_erod is set");
+    if (opts->n_periods < 0 || (opts->n_periods > 0 && !period_of_day))
+        return fail(ctx, SIMPLYP_ERR_ARG, "n_periods > 0 needs period_of_day (and n_periods must not be negative)");
     if (opts->out_slot_order && !member_of_slot)
         return fail(ctx, SIMPLYP_ERR_ARG, "out_slot_order = 1 needs member_of_slot");
     const int E = dims->E, S = dims->S, D = dims->D;
@@ -371,6 +375,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     simplyp::KernelArgs a;
     a.E = E; a.S = S; a.D = D; a.n_sets = dims->n_forcing_sets;
     a.forcing = forcing; a.doy = doy; a.forcing_of_member = forcing_of_member;
+    a.period_of_day = period_of_day; a.n_periods = opts->n_periods;
     a.mp = member_params; a.rp = reach_params;
     a.out = out; a.status = member_status;
     a.counters = (unsigned long long*)ctx->counters.ptr;
@@ -474,6 +479,8 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         }
     }
     a.out_by_slot = opts->out_slot_order ? 1 : 0;
+    if (opts->n_periods > 0)       // running sums start from zero
+        HIP_TRY(ctx, hipMemsetAsync(out, 0, (size_t)simplyp_out_bytes(dims, opts, n_out_reaches), ctx->stream));
 
     // ---- task-queue kernel: single-reach ensembles that need more waves than the chip holds at once ----
     int chunk_days = opts->time_chunk_days > 0 ? opts->time_chunk_days : 256;
@@ -548,14 +555,15 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
 }
 
 int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
-                const double* forcing, const int32_t* doy, const int32_t* forcing_of_member,
+                const double* forcing, const int32_t* doy, const int32_t* period_of_day,
+                const int32_t* forcing_of_member,
                 const double* member_params, const double* reach_params,
                 const int32_t* up_ptr, const int32_t* up_idx,
                 const int32_t* out_reaches, int32_t n_out_reaches,
                 double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals,
                 simplyp_stats* stats)
 {
-    int rc = simplyp_run_async(ctx, dims, opts, forcing, doy, forcing_of_member, member_params, reach_params,
+    int rc = simplyp_run_async(ctx, dims, opts, forcing, doy, period_of_day, forcing_of_member, member_params, reach_params,
                                up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status, member_of_slot,
                                member_rhs_evals);
     if (rc != SIMPLYP_OK) return rc;

@@ -36,6 +36,8 @@ struct KernelArgs {
     int params_by_slot;             // 1: mp / rp / forcing_of_member were gathered into slot order by the host side
     const double* forcing;          // [n_sets][2][D]
     const int* doy;                 // [D]
+    const int* period_of_day;       // [D] output period of each day (time-reduced output), or nullptr
+    int n_periods;                  // 0: one output row per day; > 0: rows are sums over periods
     const int* forcing_of_member;   // [E] or nullptr
     const double* mp;               // [NP_M][E]
     const double* rp;               // [NP_R][S][E]
@@ -753,10 +755,15 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                         r[0] = yq[0]; r[(size_t)D * E] = yq[1]; r[(size_t)2 * D * E] = yq[2]; r[(size_t)3 * D * E] = yq[3];
                     }
                     if (oslot >= 0 && a.out_mask) {
-                        const size_t col_stride = (size_t)D * a.n_out_reaches * E;
-                        double* o = a.out + ((size_t)d * a.n_out_reaches + oslot) * E + (a.out_by_slot ? slot : e);
+                        // daily rows, or (time-reduced output) running sums over the day's period: the row is owned
+                        // by this member, so the read-modify-write needs no atomics; consecutive days hit the same
+                        // L2-resident line, and across time chunks the queue kernel's release/acquire covers it
+                        const bool reduce = a.n_periods > 0;
+                        const size_t row = reduce ? (size_t)a.period_of_day[d] : (size_t)d;
+                        const size_t col_stride = (size_t)(reduce ? a.n_periods : D) * a.n_out_reaches * E;
+                        double* o = a.out + (row * a.n_out_reaches + oslot) * E + (a.out_by_slot ? slot : e);
                         unsigned m = a.out_mask;
-#define PUT(col, val) if (m & (1u << (col))) { *o = (val); o += col_stride; }
+#define PUT(col, val) if (m & (1u << (col))) { *o = reduce ? *o + (val) : (val); o += col_stride; }
                         PUT(SIMPLYP_OUT_VSA, y[0]) PUT(SIMPLYP_OUT_VSS, y[1]) PUT(SIMPLYP_OUT_VG, Vg_ode)
                         PUT(SIMPLYP_OUT_VR, y[3]) PUT(SIMPLYP_OUT_QR_END, y[4]) PUT(SIMPLYP_OUT_QR, yq[0])
                         PUT(SIMPLYP_OUT_MSUS_END, y[5]) PUT(SIMPLYP_OUT_MSUS_FLUX, yq[1])

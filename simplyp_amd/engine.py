@@ -75,7 +75,7 @@ def lib():
     L.simplyp_ctx_set_stream.argtypes = [vp, vp]
     L.simplyp_out_bytes.restype = C.c_int64
     L.simplyp_out_bytes.argtypes = [C.POINTER(abi.Dims), C.POINTER(abi.Opts), C.c_int32]
-    run_args = [vp, C.POINTER(abi.Dims), C.POINTER(abi.Opts), dp, i32p, i32p, dp, dp,
+    run_args = [vp, C.POINTER(abi.Dims), C.POINTER(abi.Opts), dp, i32p, i32p, i32p, dp, dp,
                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, dp, i32p]
     L.simplyp_run.restype = C.c_int
     L.simplyp_run.argtypes = run_args + [vp, vp, C.POINTER(abi.Stats)]
@@ -170,7 +170,7 @@ class Engine(object):
         return t.to(self.tdev).contiguous()
 
     def run(self, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing_of_member=None,
-            out_reaches=None, out=None, member_rhs=None, member_of_slot=None):
+            out_reaches=None, out=None, member_rhs=None, member_of_slot=None, period_of_day=None):
         """Integrate every (member, reach) through all days on the device.
 
         forcing [n_sets,2,D], doy [D], member_params [NP_M,E], reach_params [NP_R,S,E] may be numpy
@@ -178,7 +178,9 @@ class Engine(object):
         status [E] device tensor, stats dict).  ``member_rhs``: optional int32 device tensor [E] that
         receives the per-member count of right-hand-side evaluations.  With ``opts.out_slot_order`` the
         columns of ``out`` are lane slots; ``member_of_slot`` (int32 device tensor [E], allocated here when
-        not given and returned in stats['member_of_slot']) maps them back to members.
+        not given and returned in stats['member_of_slot']) maps them back to members.  With
+        ``opts.n_periods`` > 0 and ``period_of_day`` [D] (int32), ``out`` has one row per period holding
+        the sum of the daily values of that period.
         """
         torch = self.torch
         L = lib()
@@ -187,6 +189,7 @@ class Engine(object):
         mp = self.to_device(member_params, torch.float64)
         rp = self.to_device(reach_params, torch.float64)
         fom = None if forcing_of_member is None else self.to_device(forcing_of_member, torch.int32)
+        pod = None if period_of_day is None else self.to_device(period_of_day, torch.int32)
         n_sets, two, D = f.shape
         npm, E = mp.shape
         npr, S, E2 = rp.shape
@@ -202,10 +205,13 @@ class Engine(object):
         n_or = S if oreach is None else len(oreach)
         ncols = bin(opts.out_mask).count('1')
         dims = abi.Dims(E, S, D, n_sets)
+        rows = opts.n_periods if opts.n_periods > 0 else D
+        if opts.n_periods > 0 and (pod is None or pod.shape[0] != D):
+            raise ValueError("opts.n_periods > 0 needs period_of_day with one entry per day")
         if out is None:
-            out = torch.empty((ncols, D, n_or, E), dtype=torch.float64, device=self.tdev)
-        elif tuple(out.shape) != (ncols, D, n_or, E) or out.dtype != torch.float64 or not out.is_contiguous():
-            raise ValueError("out must be a contiguous float64 device tensor of shape %s" % ((ncols, D, n_or, E),))
+            out = torch.empty((ncols, rows, n_or, E), dtype=torch.float64, device=self.tdev)
+        elif tuple(out.shape) != (ncols, rows, n_or, E) or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float64 device tensor of shape %s" % ((ncols, rows, n_or, E),))
         assert out.numel() * 8 == L.simplyp_out_bytes(C.byref(dims), C.byref(opts), n_or)
         status = torch.empty((E,), dtype=torch.int32, device=self.tdev)
         if opts.out_slot_order and member_of_slot is None:
@@ -219,6 +225,7 @@ class Engine(object):
                 torch.cuda.current_stream().synchronize()
             ip = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.POINTER(C.c_int32))
             rc = L.simplyp_run(self._h, C.byref(dims), C.byref(opts), f.data_ptr(), dy.data_ptr(),
+                               None if pod is None else pod.data_ptr(),
                                None if fom is None else fom.data_ptr(), mp.data_ptr(), rp.data_ptr(),
                                ip(up_ptr), ip(up_idx), ip(oreach), n_or, out.data_ptr(), status.data_ptr(),
                                None if member_of_slot is None else member_of_slot.data_ptr(),

@@ -126,14 +126,14 @@ def sum_to_waterbody(p_struc, n_SC, df_R_dict, f_TDP):
 # ------------------------------------------------------------------------------------------
 # the hot path
 
-def _engine_opts(p_SU, p, dynamic_options, step_len, solver, out_mask):
+def _engine_opts(p_SU, p, dynamic_options, step_len, solver, out_mask, n_periods=0):
     scs = marshal.sc_list(p)
     return abi.make_opts(solver,
                          dynamic_epc0=(dynamic_options['Dynamic_EPC0'] == 'y'),
                          dynamic_erod=(dynamic_options['Dynamic_erodibility'] == 'y'),
                          run_mode_cal=(p_SU.run_mode == 'cal'),
                          sc_qr0=scs.index(int(p['SC_Qr0'])),
-                         out_mask=out_mask, step_len=step_len)
+                         out_mask=out_mask, step_len=step_len, n_periods=n_periods)
 
 
 def _kf_last(p_SU, p_LU, p_SC, p):
@@ -229,16 +229,19 @@ def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len
 
 
 def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
-                          outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True):
+                          outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True,
+                          reduce=None):
     """Run an ensemble of parameter sets through the engine in one call.
 
     ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
     array broadcastable to [S, E] (reach parameters, ``marshal.PR_NAMES``); parameters not
     listed take the workbook value for every member.  ``outputs``: list of reference column
     names (default: the five documented reach outputs, model.py:272-277).  ``out_reaches``:
-    sub-catchment ids to return (default all).
+    sub-catchment ids to return (default all).  ``reduce``: None for daily rows, ``'annual'`` for one row
+    per calendar year holding the sum of that year's daily values (e.g. annual fluxes), or an int array
+    [D] of period indices; the periods are returned under ``'periods'``.
 
-    Returns ``dict(columns, reaches, data[n_cols, D, n_reaches, E], status[E], stats)``; ``data``
+    Returns ``dict(columns, reaches, data[n_cols, D or n_periods, n_reaches, E], status[E], stats)``; ``data``
     and ``status`` are numpy arrays, or device tensors when ``to_host`` is False.
     The caller's ``p_LU``/``p_SC`` are edited in place exactly as by ``run_simply_p``.
     """
@@ -259,12 +262,28 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     forcing, doy = marshal.forcing_arrays(met_df)
     cols = list(outputs) if outputs is not None else list(marshal.REACH5_COLUMNS)
     mask = marshal.mask_of_columns(cols)
-    opts = _engine_opts(p_SU, p, dynamic_options, step_len, solver, mask)
+    period_of_day, periods = None, None
+    if reduce is not None:
+        if isinstance(reduce, str):
+            if reduce != 'annual':
+                raise ValueError("reduce must be None, 'annual' or an array of period indices")
+            years = np.asarray(met_df.index.year)
+            periods, period_of_day = np.unique(years, return_inverse=True)
+        else:
+            period_of_day = np.asarray(reduce)
+            if period_of_day.shape != (len(met_df),) or period_of_day.min() < 0:
+                raise ValueError("reduce array needs one non-negative period index per day")
+            periods = np.arange(int(period_of_day.max()) + 1)
+        period_of_day = np.ascontiguousarray(period_of_day, dtype=np.int32)
+    opts = _engine_opts(p_SU, p, dynamic_options, step_len, solver, mask,
+                        n_periods=0 if periods is None else len(periods))
     oreach = None if out_reaches is None else [scs.index(int(r)) for r in out_reaches]
 
     eng = engine.get_engine(device)
-    out_d, status_d, stats = eng.run(forcing, doy, mp, rp, up_ptr, up_idx, opts, out_reaches=oreach)
+    out_d, status_d, stats = eng.run(forcing, doy, mp, rp, up_ptr, up_idx, opts, out_reaches=oreach,
+                                     period_of_day=period_of_day)
     marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)
     return dict(columns=marshal.columns_of_mask(mask), reaches=(scs if out_reaches is None else list(out_reaches)),
+                periods=periods,
                 data=out_d.cpu().numpy() if to_host else out_d,
                 status=status_d.cpu().numpy() if to_host else status_d, stats=stats)

@@ -394,3 +394,28 @@ def test_task_queue_kernel_is_bitwise_identical(engine0, integrator):
         assert np.array_equal(got, ref, equal_nan=True), (balance, slot_order)
         assert np.array_equal(sgot, sref) and sref[77] & abi.STATUS_NONFINITE
         assert bool(torch.equal(w0, w1)) and st['rhs_evals'] == st0['rhs_evals']
+
+
+def test_time_reduced_output_equals_sums_of_daily_rows(engine0):
+    """opts.n_periods: rows are per-period running sums accumulated in the kernel (chain kernel and task-queue
+    kernel, member order and slot order) == the daily rows summed per period on the host."""
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('tarland_1981_2010_dynamic')
+    met = met.iloc[:1500]
+    E = 130
+    rng = np.random.default_rng(31)
+    over = {'a_Q': 0.5 * rng.uniform(0.5, 2.0, E), 'fc': 290 * rng.uniform(0.8, 1.2, E)}
+    cols = ['Qr', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day', 'VsA']
+    daily = sp.run_simply_p_ensemble(met, p_struc.copy(), p_SU.copy(), p_LU.copy(), p_SC.copy(), p.copy(), dyn,
+                                     overrides=over, outputs=cols, solver=dict(time_chunk_days=-1, balance=0))
+    years = np.asarray(met.index.year)
+    uy = np.unique(years)
+    want = np.stack([daily['data'][:, years == y].sum(axis=1) for y in uy], axis=1)
+    for solver in (dict(time_chunk_days=-1, balance=0), dict(time_chunk_days=256, balance=1, balance_pilot_days=60)):
+        red = sp.run_simply_p_ensemble(met, p_struc.copy(), p_SU.copy(), p_LU.copy(), p_SC.copy(), p.copy(), dyn,
+                                       overrides=over, outputs=cols, reduce='annual', solver=solver)
+        assert list(red['periods']) == list(uy) and red['data'].shape == (5, len(uy), 1, E)
+        assert red['columns'] == daily['columns'] and red['status'].max() == 0
+        np.testing.assert_allclose(red['data'], want, rtol=1e-12)
+    with pytest.raises(ValueError):
+        sp.run_simply_p_ensemble(met, p_struc.copy(), p_SU.copy(), p_LU.copy(), p_SC.copy(), p.copy(), dyn,
+                                 overrides=over, reduce='monthly')
