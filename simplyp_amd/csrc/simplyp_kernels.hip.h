@@ -395,56 +395,47 @@ __device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], co
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b6, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e6, kq[i], eq[i]); }
 
-        double err = 0.0;
-        double yn[NS], yqn[4];
+        // increment of the 5th-order solution, embedded error estimate, scaled error norm
+        double err = 0.0, chk = 0.0;
+        double dy[NS], dq[4];
         const double hb1 = hh * b1, hb3 = hh * b3, hb4 = hh * b4, hb6 = hh * b6;
         const double he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            yn[i] = __builtin_fma(hb6, k6[i], __builtin_fma(hb4, k4[i], __builtin_fma(hb3, k3[i], __builtin_fma(hb1, k1[i], y[i]))));
+            dy[i] = __builtin_fma(hb6, k6[i], __builtin_fma(hb4, k4[i], __builtin_fma(hb3, k3[i], hb1 * k1[i])));
+            chk += dy[i];                                  // any NaN/Inf in the increment ends up here
             if (i < SYS::N_ERR) {
+                const double yn = y[i] + dy[i];
                 const double he = __builtin_fma(he1, k1[i], __builtin_fma(he3, k3[i], __builtin_fma(he4, k4[i],
                                   __builtin_fma(he5, k5[i], he6 * k6[i]))));
-                const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(y[i]), __builtin_fabs(yn[i])), atol);
+                const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(y[i]), __builtin_fabs(yn)), atol);
                 err = __builtin_fmax(err, __builtin_fabs(he) * __builtin_amdgcn_rcp(sc));
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            yqn[i] = __builtin_fma(hh, sq[i], yq[i]);
+            dq[i] = hh * sq[i];
             if (SYS::QUAD_IN_NORM) {
-                const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(yq[i]), __builtin_fabs(yqn[i])), atol);
+                const double yqn = yq[i] + dq[i];
+                const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(yq[i]), __builtin_fabs(yqn)), atol);
                 err = __builtin_fmax(err, __builtin_fabs(hh * eq[i]) * __builtin_amdgcn_rcp(sc));
             }
         }
-        // v_max_f64 drops NaNs, so test the new state itself
-        bool bad = !(err < 1.0e300);
-#pragma unroll
-        for (int i = 0; i < NS; ++i) bad = bad || !(__builtin_fabs(yn[i]) < 1.0e300);
+        // v_max_f64 drops NaNs, so the finiteness test is on the increment itself
+        const bool bad = !(err < 1.0e300) || !(__builtin_fabs(chk) < 1.0e300);
 
+        bool accept = false, give_up = false;
         if (alive) {
             ++attempts;
             cnt.rhs += 6;
             if (last_chance) cnt.capped = true;
-            const bool give_up = bad && (last_chance || hh <= 1.0e-9 * T);
-            if (give_up) {
-                // cannot be integrated: poison the state, flag the member, stop
-#pragma unroll
-                for (int i = 0; i < NS; ++i) y[i] = __builtin_nan("");
-#pragma unroll
-                for (int i = 0; i < 4; ++i) yq[i] = __builtin_nan("");
-                cnt.poisoned = true;
-                alive = false;
-            } else if (!bad && (err <= 1.0 || last_chance)) {
-#pragma unroll
-                for (int i = 0; i < NS; ++i) y[i] = yn[i];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) yq[i] = yqn[i];
+            give_up = bad && (last_chance || hh <= 1.0e-9 * T);
+            accept = !bad && (err <= 1.0 || last_chance);
+            if (accept) {
                 t = (hh == rem) ? T : t + hh;
                 ++cnt.steps;
                 ++since_sync;
-                alive = t < T;
-            } else {
+            } else if (!give_up) {
                 ++cnt.rejected;
             }
             float fac;
@@ -457,6 +448,23 @@ __device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], co
             }
             h = hh * (double)fac;
         }
+        // State update in place: y += m dy with m = 1 for lanes that accepted, 0 otherwise (no copies of the
+        // state through the loop).  0 * NaN would poison a lane that merely rejected a non-finite trial, so the
+        // rare wave that has such a lane takes the select path instead.
+        if (__any(alive && bad)) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) y[i] = give_up ? __builtin_nan("") : (accept ? y[i] + dy[i] : y[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yq[i] = give_up ? __builtin_nan("") : (accept ? yq[i] + dq[i] : yq[i]);
+            if (give_up) { cnt.poisoned = true; }
+        } else {
+            const double m = accept ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) y[i] = __builtin_fma(m, dy[i], y[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma(m, dq[i], yq[i]);
+        }
+        alive = alive && !give_up && (t < T);
         if (SYS::RESYNC_EVERY > 0) {
             const bool due = alive && since_sync >= SYS::RESYNC_EVERY;
             if (__any(due)) {
