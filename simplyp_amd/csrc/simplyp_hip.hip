@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -390,6 +391,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     a.rtol = opts->rtol; a.atol = opts->atol; a.step_len = opts->step_len;
 
     a.D_stride = D;
+    a.route_days = D;
     a.perm = nullptr;
     a.out_by_slot = 0;
     a.params_by_slot = 0;
@@ -433,6 +435,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         HIP_TRY(ctx, hipMemsetAsync(d_cost, 0, (size_t)E * sizeof(uint32_t), ctx->stream));
         simplyp::KernelArgs p = a;
         p.D = pilot_days;                 // forcing rows keep their stride of D days
+        p.route_days = pilot_days;
         p.out_mask = 0u;                  // nothing is written
         p.member_rhs = d_cost;
         rc = launch_all(p);
@@ -482,42 +485,95 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     if (opts->n_periods > 0)       // running sums start from zero
         HIP_TRY(ctx, hipMemsetAsync(out, 0, (size_t)simplyp_out_bytes(dims, opts, n_out_reaches), ctx->stream));
 
-    // ---- task-queue kernel: single-reach ensembles that need more waves than the chip holds at once ----
+    // ---- task-queue kernel: (reach, time chunk, member group) tasks pulled by one persistent wave per SIMD ----
+    // auto: when the chain kernel would leave SIMDs idle -- a single-reach ensemble that needs more waves than the chip
+    // holds at once, or a multi-reach network (a chain walked by one thread per member cannot use more than E lanes)
     int chunk_days = opts->time_chunk_days > 0 ? opts->time_chunk_days : 256;
     chunk_days = ((chunk_days + simplyp::TILE_D - 1) / simplyp::TILE_D) * simplyp::TILE_D;
-    const bool want_queue = S == 1 && opts->integrator != SIMPLYP_INTEG_RK4 && D > chunk_days &&
-        (opts->time_chunk_days > 0 || (opts->time_chunk_days == 0 && (int)gx > ctx->n_simd_slots));
+    bool want_queue = opts->integrator != SIMPLYP_INTEG_RK4 && D > chunk_days &&
+        (opts->time_chunk_days > 0 ||
+         (opts->time_chunk_days == 0 && ((S == 1 && (int)gx > ctx->n_simd_slots) || (S > 1 && (int)gx < ctx->n_simd_slots))));
     ctx->queued = 0;
     if (want_queue) {
-        const int n_groups = (int)gx, n_chunks = (D + chunk_days - 1) / chunk_days;
-        const size_t flags_bytes = (((size_t)n_groups + 2) * sizeof(unsigned) + 255) / 256 * 256;
-        rc = ensure(ctx, ctx->queue, flags_bytes + (size_t)simplyp::CKPT_N * E * sizeof(double));
-        if (rc != SIMPLYP_OK) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->queue.ptr, 0, flags_bytes, ctx->stream));
-        simplyp::QueueArgs q;
-        unsigned* flags = (unsigned*)ctx->queue.ptr;
-        q.ticket = flags; q.error = flags + 1; q.done = flags + 2;
-        q.ckpt = (double*)((char*)ctx->queue.ptr + flags_bytes);
-        q.n_groups = n_groups; q.n_chunks = n_chunks; q.chunk_days = chunk_days;
-        q.max_polls = 20000000u;          // x (s_sleep 64 ~ 2 us): a wait longer than ~40 s means something is broken
-        simplyp::KernelArgs k = a;
-        k.chain_ptr = dsched + off_cptr[0];
-        k.chain_reach = dsched + off_creach[0];
-        const unsigned workers = (unsigned)std::min(n_groups, ctx->n_simd_slots);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
-        if (opts->integrator == SIMPLYP_INTEG_CASHKARP)
-            hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
-        else
-            hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
-        HIP_TRY(ctx, hipGetLastError());
-        ctx->queued = 1;
-    } else {
+        const int G = (int)gx, n_chunks = (D + chunk_days - 1) / chunk_days;
+        // levels, ring depth, downstream CSR, routing buffers
+        std::vector<int> level(S, 0), n_down(S, 0);
+        int max_jump = 0;
+        for (int s = 0; s < S; ++s)
+            for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) level[s] = std::max(level[s], level[up_idx[k]] + 1);
+        for (int s = 0; s < S; ++s)
+            for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) { max_jump = std::max(max_jump, level[s] - level[up_idx[k]]); ++n_down[up_idx[k]]; }
+        const int ring_chunks = std::min(n_chunks, max_jump + 1);
+        std::vector<int> down_ptr(S + 1, 0), down_idx((size_t)std::max(1, (int)up_ptr[S])), qslot(S, -1);
+        for (int s = 0; s < S; ++s) down_ptr[s + 1] = down_ptr[s] + n_down[s];
+        { std::vector<int> fill(down_ptr.begin(), down_ptr.end() - 1);
+          for (int s = 0; s < S; ++s) for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) down_idx[fill[up_idx[k]]++] = s; }
+        int n_route = 0;
+        for (int s = 0; s < S; ++s) if (n_down[s] > 0) qslot[s] = n_route++;
+        const size_t ring_days = (size_t)ring_chunks * chunk_days;
+        const size_t route_bytes = (size_t)n_route * 4 * ring_days * E * sizeof(double);
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        if (route_bytes > ctx->route.bytes && route_bytes - ctx->route.bytes > free_b / 10 * 9) want_queue = false;   // does not fit: chain kernel
+        if (want_queue) {
+            // (reach, chunk) pairs in dependency order: by level + chunk, then reach
+            std::vector<int> pair_idx((size_t)S * n_chunks);
+            std::iota(pair_idx.begin(), pair_idx.end(), 0);
+            std::stable_sort(pair_idx.begin(), pair_idx.end(), [&](int x, int y) {
+                const int kx = level[x / n_chunks] + x % n_chunks, ky = level[y / n_chunks] + y % n_chunks;
+                return kx != ky ? kx < ky : x < y;
+            });
+            std::vector<int> qi;                       // task_reach | task_chunk | down_ptr | down_idx | qslot
+            for (int v : pair_idx) qi.push_back(v / n_chunks);
+            for (int v : pair_idx) qi.push_back(v % n_chunks);
+            const size_t off_dptr = qi.size(); qi.insert(qi.end(), down_ptr.begin(), down_ptr.end());
+            const size_t off_didx = qi.size(); qi.insert(qi.end(), down_idx.begin(), down_idx.end());
+            const size_t off_qslot = qi.size(); qi.insert(qi.end(), qslot.begin(), qslot.end());
+            const size_t flags_bytes = (((size_t)S * G + 2) * sizeof(unsigned) + 255) / 256 * 256;
+            const size_t ints_bytes = (qi.size() * sizeof(int) + 255) / 256 * 256;
+            rc = ensure(ctx, ctx->queue, flags_bytes + ints_bytes + (size_t)S * simplyp::CKPT_N * E * sizeof(double));
+            if (rc != SIMPLYP_OK) return rc;
+            if (route_bytes) { rc = ensure(ctx, ctx->route, route_bytes); if (rc != SIMPLYP_OK) return rc; }
+            char* base = (char*)ctx->queue.ptr;
+            HIP_TRY(ctx, hipMemsetAsync(base, 0, flags_bytes, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(base + flags_bytes, qi.data(), qi.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            simplyp::QueueArgs q;
+            unsigned* flags = (unsigned*)base;
+            const int* dq = (const int*)(base + flags_bytes);
+            q.ticket = flags; q.error = flags + 1; q.done = flags + 2;
+            q.task_reach = dq; q.task_chunk = dq + pair_idx.size();
+            q.down_ptr = dq + off_dptr; q.down_idx = dq + off_didx;
+            q.ckpt = (double*)(base + flags_bytes + ints_bytes);
+            q.n_groups = G; q.n_pairs = (int)pair_idx.size(); q.chunk_days = chunk_days; q.ring_chunks = ring_chunks;
+            q.max_polls = 20000000u;      // x (s_sleep 64 ~ 2 us): a wait longer than ~40 s means something is broken
+            if (const char* mp_env = getenv("SIMPLYP_QUEUE_MAX_POLLS")) q.max_polls = (unsigned)strtoul(mp_env, nullptr, 10);
+            simplyp::KernelArgs k = a;
+            k.route = (double*)ctx->route.ptr;
+            k.route_days = (int)ring_days;
+            k.route_slot = dq + off_qslot;
+            k.chain_ptr = nullptr; k.chain_reach = nullptr;
+            const long long n_tasks = (long long)pair_idx.size() * G;
+            unsigned workers = (unsigned)std::min<long long>(n_tasks, ctx->n_simd_slots);
+            if (const char* w_env = getenv("SIMPLYP_QUEUE_WORKERS")) workers = std::max(1u, std::min(workers, (unsigned)strtoul(w_env, nullptr, 10)));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+            if (opts->integrator == SIMPLYP_INTEG_CASHKARP)
+                hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
+            else
+                hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
+            HIP_TRY(ctx, hipGetLastError());
+            if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] queue kernel launched: S=%d G=%d pairs=%zu chunk=%d ring=%d workers=%u max_polls=%u\n", S, G, pair_idx.size(), chunk_days, ring_chunks, workers, q.max_polls);
+            ctx->queued = 1;
+            ctx->n_launches = 1;
+        }
+    }
+    if (!want_queue) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
         rc = launch_all(a);
         if (rc != SIMPLYP_OK) return rc;
+        ctx->n_launches = (int)sch.launches.size();
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
-    ctx->n_launches = (int)sch.launches.size();
     ctx->pending = true;
     return SIMPLYP_OK;
 }
@@ -528,8 +584,10 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
     if (!ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "no run pending");
     ctx->pending = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] sync: waiting for the stop event\n");
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] sync: stream idle\n");
     if (ctx->queued) {
         unsigned err = 0;
         HIP_TRY(ctx, hipMemcpy(&err, (unsigned*)ctx->queue.ptr + 1, sizeof(err), hipMemcpyDeviceToHost));

@@ -45,8 +45,9 @@ struct KernelArgs {
     int* status;                    // [E]
     unsigned* member_rhs;           // [E] or nullptr: rhs evaluations per member
     unsigned long long* counters;   // rhs, steps, rejected, wave-level attempts
-    double* route;                  // [n_slots][4][D][E] daily series handed downstream
-    const int* chain_ptr;           // [n_chains+1]   (this launch)
+    double* route;                  // [n_slots][4][route_days][E] daily series handed downstream
+    int route_days;                 // rows per series buffer: D (chain kernel) or a ring of a few time chunks (queue)
+    const int* chain_ptr;           // [n_chains+1]   (this launch; chain kernel)
     const int* chain_reach;         // reach ids in processing order
     const int* up_ptr;              // [S+1]
     const int* up_idx;              // CSR of directly-upstream reaches
@@ -506,7 +507,7 @@ constexpr int CKPT_N = 15;    // y[8], Plab_A, TDPs_A, Plab_NC, TDPs_NC, conc_A,
 
 template <int INTEG>
 __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, double* s_E, int* s_doy,
-                                         const int lane, const int slot_raw, const int chain,
+                                         const int lane, const int slot_raw, const int* reaches, const int n_reaches,
                                          const int d_begin, const int d_end, double* ckpt)
 {
     const bool active = slot_raw < a.E;
@@ -544,8 +545,9 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
     unsigned n_rhs = 0, n_steps = 0, n_rej = 0, n_trips = 0;
     int stat = 0;
 
-    for (int ci = a.chain_ptr[chain]; ci < a.chain_ptr[chain + 1]; ++ci) {
-        const int s = a.chain_reach[ci];
+    const size_t RD = (size_t)a.route_days;           // rows of a routing series buffer
+    for (int ci = 0; ci < n_reaches; ++ci) {
+        const int s = reaches[ci];
 
         // ---- per-reach constants and initial conditions (model.py:377-463) ----
         const double A_catch = RPv(SIMPLYP_PR_A_CATCH, s);
@@ -619,10 +621,11 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
         const int up_lo = a.up_ptr[s], up_hi = a.up_ptr[s + 1];
         const int rslot = a.route_slot[s];
         const int oslot = a.out_slot[s];
-        double* route_w = rslot >= 0 ? a.route + (size_t)rslot * 4 * D * E : nullptr;
+        double* route_w = rslot >= 0 ? a.route + (size_t)rslot * 4 * RD * E : nullptr;
 
         for (int d0 = d_begin; d0 < d_end; d0 += TILE_D) {
             const int nd = min(TILE_D, d_end - d0);
+
             if (shared_forcing) {
                 __syncthreads();
                 for (int i = lane; i < nd; i += WAVE) { s_P[i] = Pser[d0 + i]; s_E[i] = Eser[d0 + i]; }
@@ -639,11 +642,11 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                 double QrUS = 0.0, MsusUS = 0.0, TDPrUS = 0.0, PPrUS = 0.0;
                 for (int k = up_lo; k < up_hi; ++k) {
                     const int u = a.up_idx[k];
-                    const double* r = a.route + (size_t)a.route_slot[u] * 4 * D * E + (size_t)d * E + slot;
+                    const double* r = a.route + (size_t)a.route_slot[u] * 4 * RD * E + ((size_t)d % RD) * E + slot;
                     QrUS += r[0] * (RPv(SIMPLYP_PR_A_CATCH, u) / A_catch);                        // :524-525
-                    MsusUS += r[(size_t)D * E];
-                    TDPrUS += r[(size_t)2 * D * E];
-                    PPrUS += r[(size_t)3 * D * E];                                                // :526-528
+                    MsusUS += r[RD * E];
+                    TDPrUS += r[2 * RD * E];
+                    PPrUS += r[3 * RD * E];                                                       // :526-528
                 }
 
                 // sediment input coefficients (:549-594)
@@ -759,8 +762,8 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                 // ---- hand the daily series downstream and store the requested columns ----
                 if (active) {
                     if (route_w) {
-                        double* r = route_w + (size_t)d * E + slot;
-                        r[0] = yq[0]; r[(size_t)D * E] = yq[1]; r[(size_t)2 * D * E] = yq[2]; r[(size_t)3 * D * E] = yq[3];
+                        double* r = route_w + ((size_t)d % RD) * E + slot;
+                        r[0] = yq[0]; r[RD * E] = yq[1]; r[2 * RD * E] = yq[2]; r[3 * RD * E] = yq[3];
                     }
                     if (oslot >= 0 && a.out_mask) {
                         // daily rows, or (time-reduced output) running sums over the day's period: the row is owned
@@ -817,33 +820,69 @@ __global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
     __shared__ int s_doy[TILE_D];
-    run_slot<INTEG>(a, s_P, s_E, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, blockIdx.y, 0, a.D, nullptr);
+    const int c0 = a.chain_ptr[blockIdx.y], c1 = a.chain_ptr[blockIdx.y + 1];
+    run_slot<INTEG>(a, s_P, s_E, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
-// Work-conserving variant for single-reach ensembles that need more waves than the chip holds.
+// Work-conserving, pipelined variant: one persistent wave per SIMD pulls tasks from a ticket counter.
 //
-// The run is cut into tasks (time chunk c, member group g of 64 lane slots), numbered chunk-major.
-// One persistent wave per SIMD pulls task numbers from a ticket counter; task (c, g) needs the state task
-// (c-1, g) left in `ckpt`, which some other wave may still be computing, so the worker waits on
-// done[g] >= c.  Tickets are handed out in task order, so the task waited for always holds a smaller
-// ticket: it is running on a resident wave (or finished) and itself waits only on still smaller tickets --
-// no assumption about dispatch order or placement, no deadlock.  Every SIMD stays busy until the ticket
-// counter runs out, whatever the members' relative costs.
+// A task is (reach s, time chunk c, member group g of 64 lane slots).  It needs
+//   (s, c-1, g)            the group's own state at the chunk boundary, left in `ckpt` by whichever wave ran it;
+//   (u, c, g), u in up(s)  the upstream reaches' daily series for the chunk (routing ring buffers);
+// and, because those ring buffers hold only `ring_chunks` chunks per reach,
+//   (dn, c-ring_chunks, g), dn in down(s)   every reader of the ring rows this task is about to overwrite.
+// The host numbers the tasks by (level(s) + c, then reach, then group) -- level = longest distance from a
+// headwater -- and sizes the ring so that each of these dependencies has a SMALLER number.  Tickets are handed
+// out in task order, so whatever a wave waits for is already running on a resident wave (or finished) and itself
+// waits only on still smaller tickets: no assumption about dispatch order or placement, no deadlock.  A chain of
+// 256 reaches therefore runs as a pipeline 256 deep (reach s works on chunk c while reach s+1 works on chunk c-1),
+// and a single-reach ensemble simply keeps every SIMD busy until the tickets run out, whatever the members'
+// relative costs.
 //
 // Hand-off (MI355X_MICROARCH.md, "Valid forms"): producer = plain stores, s_waitcnt vmcnt(0), agent-scope
 // release, s_waitcnt vmcnt(0) (asm, so the compiler cannot drop it), relaxed agent-scope flag store;
-// consumer = relaxed agent-scope poll by one lane (with s_sleep), agent-scope acquire, s_waitcnt vmcnt(0),
+// consumer = relaxed agent-scope polls (wave-uniform address, with s_sleep), agent-scope acquire, s_waitcnt vmcnt(0),
 // then plain loads.  The spin is bounded: on timeout the wave raises q.error and every worker drains.
 struct QueueArgs {
     unsigned* ticket;          // next task number
-    unsigned* done;            // [n_groups] chunks completed per member group
+    unsigned* done;            // [S][n_groups] chunks completed per (reach, member group)
     unsigned* error;           // set to 1 on a wait timeout
-    double* ckpt;              // [CKPT_N][E]
-    int n_groups, n_chunks, chunk_days;
+    double* ckpt;              // [S][CKPT_N][E]
+    const int* task_reach;     // [n_pairs] reach of the (reach, chunk) pair, in dependency order
+    const int* task_chunk;     // [n_pairs]
+    const int* down_ptr;       // [S+1] CSR of directly-downstream reaches
+    const int* down_idx;
+    int n_groups, n_pairs, chunk_days, ring_chunks;
     unsigned max_polls;
 };
 
+// Wait until *flag >= need.  Executed by the whole wave on a wave-uniform address (the 64 identical loads are
+// one request) and made scalar with readfirstlane, so the spin is a scalar loop: no lane-masked control flow
+// around it.
+__device__ __forceinline__ bool queue_wait(const QueueArgs& q, const unsigned* flag, unsigned need)
+{
+    unsigned polls = 0;
+    for (;;) {
+        const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= need) return true;
+        __builtin_amdgcn_s_sleep(64);
+        const unsigned err = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_load(q.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (++polls > q.max_polls || err != 0u) return false;
+    }
+}
+
+__device__ __forceinline__ unsigned queue_take_ticket(const QueueArgs& q, int lane)
+{
+    unsigned k = 0;
+    if (lane == 0) k = atomicAdd(q.ticket, 1u);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+}
+
+// The persistent loop has a single exit, at its head, on a scalar: with `break`s in the body hipcc (ROCm 7.2)
+// structurised the ticket loop into a lane-masked inner loop that re-ran task 0 forever.
 template <int INTEG>
 __global__ __launch_bounds__(WAVE) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
 {
@@ -851,38 +890,37 @@ __global__ __launch_bounds__(WAVE) void simplyp_queue_kernel(const KernelArgs a,
     __shared__ double s_E[TILE_D];
     __shared__ int s_doy[TILE_D];
     const int lane = threadIdx.x;
-    const unsigned n_tasks = (unsigned)q.n_groups * (unsigned)q.n_chunks;
-    for (;;) {
-        unsigned k = 0;
-        if (lane == 0) k = atomicAdd(q.ticket, 1u);
-        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-        if (k >= n_tasks) break;
-        const int c = (int)(k / (unsigned)q.n_groups), g = (int)(k % (unsigned)q.n_groups);
-        if (c > 0) {
-            int ok = 1;
-            if (lane == 0) {
-                unsigned polls = 0;
-                while (__hip_atomic_load(&q.done[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c) {
-                    __builtin_amdgcn_s_sleep(64);
-                    if (++polls > q.max_polls ||
-                        __hip_atomic_load(q.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-                }
-            }
-            ok = __builtin_amdgcn_readfirstlane(ok);
-            if (!ok) {
-                if (lane == 0) __hip_atomic_store(q.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+    const unsigned G = (unsigned)q.n_groups;
+    const unsigned n_tasks = (unsigned)q.n_pairs * G;
+    unsigned k = queue_take_ticket(q, lane);
+    while (k < n_tasks) {
+        const int pair = (int)(k / G), g = (int)(k % G);
+        const int s = __builtin_amdgcn_readfirstlane(q.task_reach[pair]);
+        const int c = __builtin_amdgcn_readfirstlane(q.task_chunk[pair]);
+        bool ok = true;                       // everything here is wave-uniform
+        if (c > 0) ok = queue_wait(q, &q.done[(size_t)s * G + g], (unsigned)c);
+        for (int i = a.up_ptr[s]; ok && i < a.up_ptr[s + 1]; ++i)
+            ok = queue_wait(q, &q.done[(size_t)a.up_idx[i] * G + g], (unsigned)(c + 1));
+        if (c >= q.ring_chunks)
+            for (int i = q.down_ptr[s]; ok && i < q.down_ptr[s + 1]; ++i)
+                ok = queue_wait(q, &q.done[(size_t)q.down_idx[i] * G + g], (unsigned)(c - q.ring_chunks + 1));
+        if (ok) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int d_begin = c * q.chunk_days;
+            const int d_end = min(a.D, d_begin + q.chunk_days);
+            run_slot<INTEG>(a, s_P, s_E, s_doy, lane, g * WAVE + lane, q.task_reach + pair, 1, d_begin, d_end,
+                            q.ckpt + (size_t)s * CKPT_N * (size_t)a.E);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(&q.done[(size_t)s * G + g], (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            k = queue_take_ticket(q, lane);
+        } else {
+            if (lane == 0) __hip_atomic_store(q.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            k = n_tasks;                      // a wait timed out (or another wave raised the error flag): drain
         }
-        const int d_begin = c * q.chunk_days;
-        const int d_end = min(a.D, d_begin + q.chunk_days);
-        run_slot<INTEG>(a, s_P, s_E, s_doy, lane, g * WAVE + lane, 0, d_begin, d_end, q.ckpt);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&q.done[g], (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -419,3 +419,47 @@ def test_time_reduced_output_equals_sums_of_daily_rows(engine0):
     with pytest.raises(ValueError):
         sp.run_simply_p_ensemble(met, p_struc.copy(), p_SU.copy(), p_LU.copy(), p_SC.copy(), p.copy(), dyn,
                                  overrides=over, reduce='monthly')
+
+
+@pytest.mark.parametrize('name', ['chain4_val_2004', 'confluence3_nc_2004'])
+def test_pipelined_queue_on_reach_networks_is_bitwise_identical(engine0, name):
+    """Multi-reach networks through the task-queue kernel: (reach, chunk, group) tasks in dependency order,
+    upstream series through ring buffers of a few chunks, state handed over between chunks.  Same results bit for
+    bit as the chain kernel (one thread walking its reaches upstream to downstream)."""
+    E = 150
+    m = helpers.marshal_scenario(name, E=E, solver=dict(time_chunk_days=-1, balance=0))
+    m['forcing'] = np.ascontiguousarray(np.tile(m['forcing'], (1, 1, 4)))          # 1464 days = 6 chunks of 256
+    m['doy'] = np.ascontiguousarray(np.tile(m['doy'], 4))
+    rng = np.random.default_rng(37)
+    for pname, lo, hi in (('a_Q', 0.6, 1.6), ('T_s_A', 0.5, 2.0), ('fc', 0.8, 1.2)):
+        m['member_params'][marshal.PM_NAMES.index(pname)] *= rng.uniform(lo, hi, E)
+    ref, sref, st0 = gpu_run(engine0, m)
+    assert st0['queued'] == 0 and sref.max() == 0
+    for balance in (0, 1):
+        m['opts'].time_chunk_days = 256
+        m['opts'].balance = balance
+        m['opts'].balance_pilot_days = 80
+        got, sgot, st = gpu_run(engine0, m)
+        assert st['queued'] == 1 and st['n_launches'] == 1 and st['balanced'] == balance
+        assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(sgot, sref)
+        assert st['rhs_evals'] == st0['rhs_evals']
+
+
+def test_c4_chain_pipelined_matches_chain_kernel_and_oracle(engine0, oracle_lib):
+    """BASELINE config C4's shape through the pipelined queue (auto: a 256-reach chain with few members cannot fill
+    the chip from one thread per member): 256-deep pipeline, 2-chunk routing rings; equals the in-kernel chain walk
+    bit for bit and the oracle to 10 x rtol."""
+    pr = synthetic.c4_problem(70, n_reaches=256, n_days=1100)
+    out, status, st = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'],
+                                  pr['up_ptr'], pr['up_idx'], pr['opts'], out_reaches=pr['out_reaches'])
+    assert st['queued'] == 1 and int(status.max()) == 0
+    pr['opts'].time_chunk_days = -1
+    ref, _, st0 = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'],
+                              pr['up_ptr'], pr['up_idx'], pr['opts'], out_reaches=pr['out_reaches'])
+    assert st0['queued'] == 0
+    import torch
+    assert bool(torch.equal(out, ref))
+    pick = [5, 64]
+    sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
+    cref, _, _ = cpu_run(oracle_lib, sub, out_reaches=pr['out_reaches'], n_threads=2)
+    assert helpers.max_rel_err(out.cpu().numpy()[..., pick], cref, floor=FLOOR) < 1e-7
