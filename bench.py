@@ -48,10 +48,18 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
                          % (args.gpus, world))
+    # one rank per GPU; SIMPLYP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get('SIMPLYP_BENCH_BACKEND', 'nccl')
+    n_dev = torch.cuda.device_count()
+    if backend == 'gloo':
+        local_rank = local_rank % max(n_dev, 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from simplyp_amd import engine, ensemble, marshal, synthetic
 
@@ -69,7 +77,10 @@ def main():
         by_slot = ensemble.member_summaries(o)                    # [5, 1, E] per-slot totals
         summ = torch.empty_like(by_slot)
         summ[..., stats['member_of_slot'].long()] = by_slot       # -> member order
-        total = ensemble.gather_to_root(summ, E * world) if world > 1 else summ
+        if world > 1:       # the one exchange step: per-member summaries to rank 0 (RCCL over xGMI)
+            total = ensemble.gather_to_root(summ if backend == 'nccl' else summ.cpu(), E * world)
+        else:
+            total = summ
         return status, stats, total
 
     def fence():
@@ -88,7 +99,7 @@ def main():
         rhs = stats['rhs_evals']
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev if backend == 'nccl' else 'cpu')
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
