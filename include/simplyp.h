@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 8
+#define SIMPLYP_ABI_VERSION 9
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -84,10 +84,14 @@ typedef enum {
     SIMPLYP_INTEG_RK4 = 0,       /* classical RK4, `substeps` equal steps per day            */
     SIMPLYP_INTEG_CASHKARP = 1,  /* Cash-Karp 5(4) embedded pair, per-thread step control, on the reference's
                                     12-variable system as written (ode_f, model.py:58-187)                       */
-    SIMPLYP_INTEG_CASHKARP_AUG = 2 /* same pair and step rule on the augmented form of that system: exp(-mu Vs),
+    SIMPLYP_INTEG_CASHKARP_AUG = 2, /* same pair and step rule on the augmented form of that system: exp(-mu Vs),
                                     Qr**b_Q, Qr**k_M carried as extra states through their own exact ODEs and
                                     re-evaluated every day, Vr taken from its invariant -- no transcendental in
                                     the right-hand side.  Default.                        */
+    SIMPLYP_INTEG_CASHKARP_AUG_F32 = 3 /* scheme 2 with the stage arithmetic in fp32 (BASELINE config C5): 11 float states per
+                                    member inside the day's integration; the four daily integrals, the carried state,
+                                    labile soil P / soil-water TDP and the day constants stay fp64.  Meant for
+                                    rtol ~ 1e-5 (rtol < 1e-6 is refused); not a parity-grade mode.                 */
 } simplyp_integrator;
 
 typedef struct {

@@ -2,13 +2,14 @@
 
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1
 INTEG_CASHKARP_AUG = 2
+INTEG_CASHKARP_AUG_F32 = 3
 INTEGRATORS = {'rk4': INTEG_RK4, 'cashkarp': INTEG_CASHKARP, 'ck45': INTEG_CASHKARP,
-               'cashkarp_aug': INTEG_CASHKARP_AUG}
+               'cashkarp_aug': INTEG_CASHKARP_AUG, 'cashkarp_aug_f32': INTEG_CASHKARP_AUG_F32}
 
 STATUS_NONFINITE = 1
 STATUS_STEPCAP = 2

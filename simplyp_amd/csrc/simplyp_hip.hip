@@ -184,12 +184,14 @@ int check_args(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* o
     if (!forcing || !mp || !rp || !up_ptr || !out || !status)
         return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
     if (opts->integrator != SIMPLYP_INTEG_RK4 && opts->integrator != SIMPLYP_INTEG_CASHKARP &&
-        opts->integrator != SIMPLYP_INTEG_CASHKARP_AUG)
+        opts->integrator != SIMPLYP_INTEG_CASHKARP_AUG && opts->integrator != SIMPLYP_INTEG_CASHKARP_AUG_F32)
         return fail(ctx, SIMPLYP_ERR_ARG, "unknown integrator %d", opts->integrator);
     if (opts->integrator == SIMPLYP_INTEG_RK4 && opts->substeps <= 0)
         return fail(ctx, SIMPLYP_ERR_ARG, "RK4 needs substeps >= 1 (got %d)", opts->substeps);
     if (opts->integrator != SIMPLYP_INTEG_RK4 && (!(opts->rtol > 0.0) || !(opts->atol >= 0.0) || opts->max_steps < 1))
         return fail(ctx, SIMPLYP_ERR_ARG, "Cash-Karp needs rtol > 0, atol >= 0, max_steps >= 1");
+    if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32 && opts->rtol < 1e-6)
+        return fail(ctx, SIMPLYP_ERR_ARG, "fp32 stages cannot resolve rtol < 1e-6 (got %g): use integrator 2", opts->rtol);
     if (!(opts->step_len > 0.0)) return fail(ctx, SIMPLYP_ERR_ARG, "step_len must be > 0");
     if (opts->sc_qr0 < 0 || opts->sc_qr0 >= dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "sc_qr0 out of range");
     if ((opts->out_mask & SIMPLYP_MASK_ALL) == 0u || (opts->out_mask & ~SIMPLYP_MASK_ALL) != 0u)
@@ -408,6 +410,8 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
                 hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_RK4>, grid, block, 0, ctx->stream, k);
             else if (opts->integrator == SIMPLYP_INTEG_CASHKARP)
                 hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP>, grid, block, 0, ctx->stream, k);
+            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32)
+                hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP_AUG_F32>, grid, block, 0, ctx->stream, k);
             else
                 hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP_AUG>, grid, block, 0, ctx->stream, k);
             HIP_TRY(ctx, hipGetLastError());
@@ -559,6 +563,8 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
             HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
             if (opts->integrator == SIMPLYP_INTEG_CASHKARP)
                 hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
+            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32)
+                hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG_F32>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
             else
                 hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
             HIP_TRY(ctx, hipGetLastError());

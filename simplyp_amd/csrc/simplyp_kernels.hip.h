@@ -247,11 +247,28 @@ __device__ __forceinline__ void rk4_day(double (&y)[8], double (&yq)[4], const D
     }
 }
 
+// ---- scalar helpers overloaded on the working precision of an integrator -------------------------------
+__device__ __forceinline__ double sp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float sp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double sp_max(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float sp_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double sp_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float sp_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double sp_abs(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ float sp_abs(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ double sp_rcp_fast(double a) { return __builtin_amdgcn_rcp(a); }     // error-norm scale only
+__device__ __forceinline__ float sp_rcp_fast(float a) { return __builtin_amdgcn_rcpf(a); }
+template <typename R> __device__ __forceinline__ R sp_huge();
+template <> __device__ __forceinline__ double sp_huge<double>() { return 1.0e300; }
+template <> __device__ __forceinline__ float sp_huge<float>() { return 1.0e30f; }
+
 // The augmented form of the same system (SIMPLYP_INTEG_CASHKARP_AUG; derivation and pinning:
 // oracle/simplyp_oracle.c `ode_aug`): exp(-mu Vs), Qr**b_Q, Qr**k_M are carried as extra states through
 // their exact ODEs, Vr comes from its invariant, so the right-hand side is ~70 multiply-adds and one
 // reciprocal.  State z[11] = VsA VsS Vg Qr Msus TDPr PPr EA ES pb pk.
 struct SysLiteral {
+    typedef double real;
+    typedef DayConst dayconst;
     static constexpr int NS = 8;
     static constexpr int RESYNC_EVERY = 0;
     static constexpr int N_ERR = 8;             // all 8 states and the 4 daily integrals enter the error norm
@@ -264,6 +281,8 @@ struct SysLiteral {
 };
 
 struct SysAug {
+    typedef double real;
+    typedef DayConst dayconst;
     static constexpr int NS = 11;
     // pb, pk are only neutrally stable about Qr**b_Q, Qr**k_M: re-evaluate them every 16 accepted steps
     // (a storm day can take 100+), as the oracle does
@@ -306,32 +325,104 @@ struct SysAug {
     }
 };
 
+
+// fp32 working precision for the augmented system (SIMPLYP_INTEG_CASHKARP_AUG_F32, BASELINE config C5): the 11 stage
+// states and all stage arithmetic in float (half the registers, twice the VALU rate once two waves share a SIMD);
+// the four daily integrals are accumulated in fp64, and everything outside the day's integration -- the carried
+// state, labile soil P and soil-water TDP (whose daily increments are ~1e-4 of their size), the day constants --
+// stays fp64.
+struct DayConstF {
+    float c0, aE, mu, fc, inv_d, invTsA, invTsS, invTg, Qgmin, inv_dg, beta, fA, fS, qin, omb, cQ, bQ, kM,
+          Esum, MsusUS, tA, tS, tg, tconst, cPP, PPrUS, invKv;
+    __device__ __forceinline__ explicit DayConstF(const DayConst& c)
+        : c0((float)c.c0), aE((float)c.aE), mu((float)c.mu), fc((float)c.fc), inv_d((float)c.inv_d),
+          invTsA((float)c.invTsA), invTsS((float)c.invTsS), invTg((float)c.invTg), Qgmin((float)c.Qgmin),
+          inv_dg((float)__builtin_fmin(c.inv_dg, 1.0e30)), beta((float)c.beta), fA((float)c.fA), fS((float)c.fS),
+          qin((float)c.qin), omb((float)c.omb), cQ((float)c.cQ), bQ((float)c.bQ), kM((float)c.kM),
+          Esum((float)c.Esum), MsusUS((float)c.MsusUS), tA((float)c.tA), tS((float)c.tS), tg((float)c.tg),
+          tconst((float)c.tconst), cPP((float)c.cPP), PPrUS((float)c.PPrUS), invKv((float)c.invKv) {}
+};
+
+__device__ __forceinline__ float gate(float u, float inv_d)
+{
+    float s = u * inv_d;
+    s = __builtin_fminf(__builtin_fmaxf(s, 0.0f), 1.0f);
+    return s * s * __builtin_fmaf(-2.0f, s, 3.0f);
+}
+
+struct SysAugF {
+    typedef float real;
+    typedef DayConstF dayconst;
+    static constexpr int NS = 11;
+    static constexpr int RESYNC_EVERY = 16;
+    static constexpr int N_ERR = 7;
+    static constexpr bool QUAD_IN_NORM = false;
+    static __device__ __forceinline__ void resync(float (&z)[11], const DayConstF& c)
+    {
+        const float lq = __logf(z[3]);
+        z[9] = __expf(c.bQ * lq);
+        z[10] = __expf(c.kM * lq);
+    }
+    static __device__ __forceinline__ void f(const float (&z)[11], const DayConstF& c, float (&dz)[11], float (&q)[4])
+    {
+        const float uA = z[0] - c.fc, uS = z[1] - c.fc;
+        const float QsA = uA * gate(uA, c.inv_d) * c.invTsA;
+        const float QsS = uS * gate(uS, c.inv_d) * c.invTsS;
+        dz[0] = __builtin_fmaf(c.aE, z[7] - 1.0f, c.c0) - QsA;
+        dz[1] = __builtin_fmaf(c.aE, z[8] - 1.0f, c.c0) - QsS;
+        const float Qsum = __builtin_fmaf(c.fA, QsA, c.fS * QsS);
+        const float ug = __builtin_fmaf(z[2], c.invTg, -c.Qgmin);
+        const float Qg = __builtin_fmaf(gate(ug, c.inv_dg), ug, c.Qgmin);
+        dz[2] = __builtin_fmaf(c.beta, Qsum, -Qg);
+        const float Qr = z[3], pb = z[9], pk = z[10];
+        const float inflow = __builtin_fmaf(c.omb, Qsum, c.qin) + Qg - Qr;
+        const float dQr = inflow * c.cQ * pb;
+        dz[3] = dQr;
+        const float kap = pb * c.invKv;
+        const float oM = z[4] * kap, oT = z[5] * kap, oP = z[6] * kap;
+        dz[4] = __builtin_fmaf(c.Esum, pk, c.MsusUS) - oM;
+        dz[5] = __builtin_fmaf(c.tA, QsA, __builtin_fmaf(c.tS, QsS, __builtin_fmaf(c.tg, Qg, c.tconst))) - oT;
+        dz[6] = __builtin_fmaf(c.cPP, pk, c.PPrUS) - oP;
+        dz[7] = -c.mu * z[7] * dz[0];
+        dz[8] = -c.mu * z[8] * dz[1];
+        float rq = __builtin_amdgcn_rcpf(Qr);
+        rq = __builtin_fmaf(__builtin_fmaf(-Qr, rq, 1.0f), rq, rq);
+        const float r = dQr * rq;
+        dz[9] = c.bQ * pb * r;
+        dz[10] = c.kM * pk * r;
+        q[0] = Qr; q[1] = oM; q[2] = oT; q[3] = oP;
+    }
+};
+
 // Cash-Karp 5(4), per-lane step control; the rule is documented (and mirrored for the parity
 // tests) in oracle/simplyp_oracle.c `cashkarp_day` / `cashkarp_aug_day`.  Lanes that have reached T idle
 // with a zero step until the slowest lane of the wavefront is done.
 struct CkCounters { unsigned rhs, steps, rejected, wave_trips; bool capped, poisoned; };
 
 template <class SYS>
-__device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], const DayConst& c, double T,
-                                       double rtol, double atol, int max_steps, double& h_carry, CkCounters& cnt)
+__device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double (&yq)[4], const typename SYS::dayconst& c,
+                                       const double T_, const double rtol_, const double atol_, int max_steps, double& h_carry,
+                                       CkCounters& cnt)
 {
+    typedef typename SYS::real R;       // working precision of the stages (the daily integrals yq stay fp64)
     constexpr int NS = SYS::NS;
-    constexpr double a21 = 1.0 / 5;
-    constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
-    constexpr double a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
-    constexpr double a51 = -11.0 / 54, a52 = 5.0 / 2, a53 = -70.0 / 27, a54 = 35.0 / 27;
-    constexpr double a61 = 1631.0 / 55296, a62 = 175.0 / 512, a63 = 575.0 / 13824, a64 = 44275.0 / 110592, a65 = 253.0 / 4096;
-    constexpr double b1 = 37.0 / 378, b3 = 250.0 / 621, b4 = 125.0 / 594, b6 = 512.0 / 1771;
-    constexpr double e1 = 37.0 / 378 - 2825.0 / 27648, e3 = 250.0 / 621 - 18575.0 / 48384,
+    const R T = (R)T_, rtol = (R)rtol_, atol = (R)atol_;
+    constexpr R a21 = 1.0 / 5;
+    constexpr R a31 = 3.0 / 40, a32 = 9.0 / 40;
+    constexpr R a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
+    constexpr R a51 = -11.0 / 54, a52 = 5.0 / 2, a53 = -70.0 / 27, a54 = 35.0 / 27;
+    constexpr R a61 = 1631.0 / 55296, a62 = 175.0 / 512, a63 = 575.0 / 13824, a64 = 44275.0 / 110592, a65 = 253.0 / 4096;
+    constexpr R b1 = 37.0 / 378, b3 = 250.0 / 621, b4 = 125.0 / 594, b6 = 512.0 / 1771;
+    constexpr R e1 = 37.0 / 378 - 2825.0 / 27648, e3 = 250.0 / 621 - 18575.0 / 48384,
                      e4 = 125.0 / 594 - 13525.0 / 55296, e5 = -277.0 / 14336, e6 = 512.0 / 1771 - 1.0 / 4;
 
-    double t = 0.0, h = h_carry;
-    if (!(h > 0.0) || h > T) h = T;
+    R t = 0, h = (R)h_carry;
+    if (!(h > (R)0) || h > T) h = T;
     int attempts = 0, since_sync = 0;
     bool alive = true;
     // a member whose state is already non-finite is not integrated further
 #pragma unroll
-    for (int i = 0; i < NS; ++i) alive = alive && (__builtin_fabs(y[i]) < 1.0e300);
+    for (int i = 0; i < NS; ++i) alive = alive && (sp_abs(y[i]) < sp_huge<R>());
     if (!alive) {
         cnt.poisoned = true;
 #pragma unroll
@@ -340,98 +431,98 @@ __device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], co
 
     while (__any(alive)) {
         ++cnt.wave_trips;                 // one attempt issued for the whole wavefront, whoever still needs it
-        const double rem = T - t;
-        double hh = h;
-        if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
+        const R rem = T - t;
+        R hh = h;
+        if (rem <= (R)1.1 * h) hh = rem; else if (rem < (R)2 * h) hh = (R)0.5 * rem;
         const bool last_chance = (attempts + 1 >= max_steps);
         if (last_chance) hh = rem;
-        if (!alive) hh = 0.0;
+        if (!alive) hh = 0;
 
-        double k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], kq[4], yt[NS];
-        double sq[4], eq[4];                          // sum b_s kq_s, sum e_s kq_s
+        R k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], kq[4], yt[NS];
+        R sq[4], eq[4];                          // sum b_s kq_s, sum e_s kq_s
         // stage weights premultiplied by the step (per lane): one FMA per (component, earlier stage)
         SYS::f(y, c, k1, kq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = b1 * kq[i]; if (SYS::QUAD_IN_NORM) eq[i] = e1 * kq[i]; }
         {
-            const double h21 = hh * a21;
+            const R h21 = hh * a21;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) yt[i] = __builtin_fma(h21, k1[i], y[i]);
+            for (int i = 0; i < NS; ++i) yt[i] = sp_fma(h21, k1[i], y[i]);
         }
         SYS::f(yt, c, k2, kq);
         {
-            const double h31 = hh * a31, h32 = hh * a32;
+            const R h31 = hh * a31, h32 = hh * a32;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) yt[i] = __builtin_fma(h32, k2[i], __builtin_fma(h31, k1[i], y[i]));
+            for (int i = 0; i < NS; ++i) yt[i] = sp_fma(h32, k2[i], sp_fma(h31, k1[i], y[i]));
         }
         SYS::f(yt, c, k3, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b3, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e3, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(b3, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e3, kq[i], eq[i]); }
         {
-            const double h41 = hh * a41, h42 = hh * a42, h43 = hh * a43;
+            const R h41 = hh * a41, h42 = hh * a42, h43 = hh * a43;
 #pragma unroll
             for (int i = 0; i < NS; ++i)
-                yt[i] = __builtin_fma(h43, k3[i], __builtin_fma(h42, k2[i], __builtin_fma(h41, k1[i], y[i])));
+                yt[i] = sp_fma(h43, k3[i], sp_fma(h42, k2[i], sp_fma(h41, k1[i], y[i])));
         }
         SYS::f(yt, c, k4, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b4, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e4, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(b4, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e4, kq[i], eq[i]); }
         {
-            const double h51 = hh * a51, h52 = hh * a52, h53 = hh * a53, h54 = hh * a54;
+            const R h51 = hh * a51, h52 = hh * a52, h53 = hh * a53, h54 = hh * a54;
 #pragma unroll
             for (int i = 0; i < NS; ++i)
-                yt[i] = __builtin_fma(h54, k4[i], __builtin_fma(h53, k3[i], __builtin_fma(h52, k2[i], __builtin_fma(h51, k1[i], y[i]))));
+                yt[i] = sp_fma(h54, k4[i], sp_fma(h53, k3[i], sp_fma(h52, k2[i], sp_fma(h51, k1[i], y[i]))));
         }
         SYS::f(yt, c, k5, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e5, kq[i], eq[i]);
+        for (int i = 0; i < 4; ++i) if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e5, kq[i], eq[i]);
         {
-            const double h61 = hh * a61, h62 = hh * a62, h63 = hh * a63, h64 = hh * a64, h65 = hh * a65;
+            const R h61 = hh * a61, h62 = hh * a62, h63 = hh * a63, h64 = hh * a64, h65 = hh * a65;
 #pragma unroll
             for (int i = 0; i < NS; ++i)
-                yt[i] = __builtin_fma(h65, k5[i], __builtin_fma(h64, k4[i], __builtin_fma(h63, k3[i],
-                        __builtin_fma(h62, k2[i], __builtin_fma(h61, k1[i], y[i])))));
+                yt[i] = sp_fma(h65, k5[i], sp_fma(h64, k4[i], sp_fma(h63, k3[i],
+                        sp_fma(h62, k2[i], sp_fma(h61, k1[i], y[i])))));
         }
         SYS::f(yt, c, k6, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = __builtin_fma(b6, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = __builtin_fma(e6, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(b6, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e6, kq[i], eq[i]); }
 
         // increment of the 5th-order solution, embedded error estimate, scaled error norm
-        double err = 0.0, chk = 0.0;
-        double dy[NS], dq[4];
-        const double hb1 = hh * b1, hb3 = hh * b3, hb4 = hh * b4, hb6 = hh * b6;
-        const double he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
+        R err = 0, chk = 0;
+        R dy[NS], dq[4];
+        const R hb1 = hh * b1, hb3 = hh * b3, hb4 = hh * b4, hb6 = hh * b6;
+        const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            dy[i] = __builtin_fma(hb6, k6[i], __builtin_fma(hb4, k4[i], __builtin_fma(hb3, k3[i], hb1 * k1[i])));
+            dy[i] = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], hb1 * k1[i])));
             chk += dy[i];                                  // any NaN/Inf in the increment ends up here
             if (i < SYS::N_ERR) {
-                const double yn = y[i] + dy[i];
-                const double he = __builtin_fma(he1, k1[i], __builtin_fma(he3, k3[i], __builtin_fma(he4, k4[i],
-                                  __builtin_fma(he5, k5[i], he6 * k6[i]))));
-                const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(y[i]), __builtin_fabs(yn)), atol);
-                err = __builtin_fmax(err, __builtin_fabs(he) * __builtin_amdgcn_rcp(sc));
+                const R yn = y[i] + dy[i];
+                const R he = sp_fma(he1, k1[i], sp_fma(he3, k3[i], sp_fma(he4, k4[i],
+                                  sp_fma(he5, k5[i], he6 * k6[i]))));
+                const R sc = sp_fma(rtol, sp_max(sp_abs(y[i]), sp_abs(yn)), atol);
+                err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dq[i] = hh * sq[i];
             if (SYS::QUAD_IN_NORM) {
-                const double yqn = yq[i] + dq[i];
-                const double sc = __builtin_fma(rtol, __builtin_fmax(__builtin_fabs(yq[i]), __builtin_fabs(yqn)), atol);
-                err = __builtin_fmax(err, __builtin_fabs(hh * eq[i]) * __builtin_amdgcn_rcp(sc));
+                const R yq0 = (R)yq[i], yqn = yq0 + dq[i];
+                const R sc = sp_fma(rtol, sp_max(sp_abs(yq0), sp_abs(yqn)), atol);
+                err = sp_max(err, sp_abs(hh * eq[i]) * sp_rcp_fast(sc));
             }
         }
         // v_max_f64 drops NaNs, so the finiteness test is on the increment itself
-        const bool bad = !(err < 1.0e300) || !(__builtin_fabs(chk) < 1.0e300);
+        const bool bad = !(err < sp_huge<R>()) || !(sp_abs(chk) < sp_huge<R>());
 
         bool accept = false, give_up = false;
         if (alive) {
             ++attempts;
             cnt.rhs += 6;
             if (last_chance) cnt.capped = true;
-            give_up = bad && (last_chance || hh <= 1.0e-9 * T);
-            accept = !bad && (err <= 1.0 || last_chance);
+            give_up = bad && (last_chance || hh <= (R)1.0e-9 * T);
+            accept = !bad && (err <= (R)1 || last_chance);
             if (accept) {
                 t = (hh == rem) ? T : t + hh;
                 ++cnt.steps;
@@ -441,29 +532,29 @@ __device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], co
             }
             float fac;
             if (bad) fac = 0.2f;
-            else if (err == 0.0) fac = 5.0f;
+            else if (err == (R)0) fac = 5.0f;
             else {
                 // 0.9 err^(-1/5) in fp32 (v_log_f32 / v_exp_f32): a step-size factor needs no more
                 fac = 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f((float)err));
                 fac = fminf(fmaxf(fac, 0.2f), 5.0f);
             }
-            h = hh * (double)fac;
+            h = hh * (R)fac;
         }
         // State update in place: y += m dy with m = 1 for lanes that accepted, 0 otherwise (no copies of the
         // state through the loop).  0 * NaN would poison a lane that merely rejected a non-finite trial, so the
         // rare wave that has such a lane takes the select path instead.
         if (__any(alive && bad)) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) y[i] = give_up ? __builtin_nan("") : (accept ? y[i] + dy[i] : y[i]);
+            for (int i = 0; i < NS; ++i) y[i] = give_up ? (R)__builtin_nanf("") : (accept ? y[i] + dy[i] : y[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) yq[i] = give_up ? __builtin_nan("") : (accept ? yq[i] + dq[i] : yq[i]);
+            for (int i = 0; i < 4; ++i) yq[i] = give_up ? __builtin_nan("") : (accept ? yq[i] + (double)dq[i] : yq[i]);
             if (give_up) { cnt.poisoned = true; }
         } else {
-            const double m = accept ? 1.0 : 0.0;
+            const R m = accept ? (R)1 : (R)0;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) y[i] = __builtin_fma(m, dy[i], y[i]);
+            for (int i = 0; i < NS; ++i) y[i] = sp_fma(m, dy[i], y[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma(m, dq[i], yq[i]);
+            for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma((double)m, (double)dq[i], yq[i]);
         }
         alive = alive && !give_up && (t < T);
         if (SYS::RESYNC_EVERY > 0) {
@@ -473,7 +564,7 @@ __device__ __forceinline__ void ck_day(double (&y)[SYS::NS], double (&yq)[4], co
             }
         }
     }
-    h_carry = h;
+    h_carry = (double)h;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -715,6 +806,24 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
                     if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));
+                } else if (INTEG == SIMPLYP_INTEG_CASHKARP_AUG_F32) {
+                    // fp32 stages: carried state and day constants are rounded to float for the day's integration
+                    float z[11];
+                    z[0] = (float)y[0]; z[1] = (float)y[1]; z[2] = (float)y[2]; z[3] = (float)y[4];
+                    z[4] = (float)y[5]; z[5] = (float)y[6]; z[6] = (float)y[7];
+                    double ea, es, pb0, pk0;
+                    sp_exp2(-mu * y[0], -mu * y[1], ea, es);
+                    const double lq0 = sp_log(y[4]);
+                    sp_exp2(b_Q * lq0, k_M * lq0, pb0, pk0);
+                    z[7] = (float)ea; z[8] = (float)es; z[9] = (float)pb0; z[10] = (float)pk0;
+                    const DayConstF cf(c);
+                    CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
+                    ck_day<SysAugF>(z, yq, cf, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
+                    n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
+                    if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
+                    if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
+                    y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
+                    y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));                  // Vr on its invariant
                 } else {
                     // augmented form: the auxiliary states are re-evaluated exactly from VsA, VsS, Qr every day
                     double z[11];
@@ -814,8 +923,9 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
     if (active && a.member_rhs) atomicAdd(&a.member_rhs[e], n_rhs);      // several chains / time chunks per member
 }
 
+// fp64 schemes need ~500 registers for the Cash-Karp stages (one wave per SIMD); the fp32 scheme is asked to fit two
 template <int INTEG>
-__global__ __launch_bounds__(WAVE) void simplyp_chain_kernel(const KernelArgs a)
+__global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs a)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
@@ -884,7 +994,7 @@ __device__ __forceinline__ unsigned queue_take_ticket(const QueueArgs& q, int la
 // The persistent loop has a single exit, at its head, on a scalar: with `break`s in the body hipcc (ROCm 7.2)
 // structurised the ticket loop into a lane-masked inner loop that re-ran task 0 forever.
 template <int INTEG>
-__global__ __launch_bounds__(WAVE) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
+__global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];

@@ -9,6 +9,9 @@ Tolerances (fp64):
     10 x rtol at working tolerances;
   * kernel vs reference odeint(rtol=atol=1e-12), default solver: 1e-6 relative on every reach output
     (north_star's bar).
+Reduced precision (integrator 'cashkarp_aug_f32', BASELINE config C5: fp32 stages, fp64 daily integrals and soil P):
+not a parity-grade mode; 5e-4 relative against the reference at rtol 1e-5 (the error is the tolerance's, the fp64
+scheme at the same rtol has the same), stated in test_fp32_stage_mode.
 """
 
 import numpy as np
@@ -167,6 +170,9 @@ def test_argument_errors_come_back_as_exceptions(engine0):
     bad = abi.make_opts(dict(integrator='rk4', substeps=0))
     with pytest.raises(engine.EngineError, match='substeps'):
         engine0.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], bad)
+    with pytest.raises(engine.EngineError, match='fp32'):      # default rtol 1e-8 is out of reach of fp32 stages
+        engine0.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'],
+                    abi.make_opts(dict(integrator='cashkarp_aug_f32')))
     with pytest.raises(engine.EngineError, match='upstream'):
         m3 = helpers.marshal_scenario('confluence3_nc_2004', E=2)
         engine0.run(m3['forcing'], m3['doy'], m3['member_params'], m3['reach_params'],
@@ -360,7 +366,7 @@ def test_slot_order_output_mode(engine0):
     assert np.array_equal(st['member_of_slot'].cpu().numpy(), np.arange(E)) and np.array_equal(c, a)
 
 
-@pytest.mark.parametrize('integrator', ['cashkarp_aug', 'cashkarp'])
+@pytest.mark.parametrize('integrator', ['cashkarp_aug', 'cashkarp', 'cashkarp_aug_f32'])
 def test_task_queue_kernel_is_bitwise_identical(engine0, integrator):
     """opts.time_chunk_days > 0: the run is cut into (time chunk x 64-member group) tasks pulled by persistent
     waves, state handed over through memory between chunks.  Same results bit for bit, with and without the
@@ -368,7 +374,8 @@ def test_task_queue_kernel_is_bitwise_identical(engine0, integrator):
     import torch
     E = 300                                         # 5 groups, the last one ragged (44 lanes)
     name = 'tarland_1981_2010_dynamic'
-    base = helpers.marshal_scenario(name, E=E, out_mask=marshal.MASK_REACH5, solver=dict(integrator=integrator, balance=0, time_chunk_days=-1))
+    tol = dict(rtol=1e-5, atol=1e-7) if integrator.endswith('f32') else {}
+    base = helpers.marshal_scenario(name, E=E, out_mask=marshal.MASK_REACH5, solver=dict(tol, integrator=integrator, balance=0, time_chunk_days=-1))
     D = 2200                                        # 9 chunks of 256 days (the last one short)
     base['forcing'] = np.ascontiguousarray(base['forcing'][:, :, :D])
     base['doy'] = np.ascontiguousarray(base['doy'][:D])
@@ -381,7 +388,7 @@ def test_task_queue_kernel_is_bitwise_identical(engine0, integrator):
     assert st0['queued'] == 0
     for balance, slot_order in ((0, 0), (1, 0), (1, 1)):
         m = dict(base)
-        m['opts'] = abi.make_opts(dict(integrator=integrator, balance=balance, balance_pilot_days=100, time_chunk_days=256,
+        m['opts'] = abi.make_opts(dict(tol, integrator=integrator, balance=balance, balance_pilot_days=100, time_chunk_days=256,
                                        out_slot_order=slot_order), dynamic_epc0=True, dynamic_erod=True,
                                   out_mask=marshal.MASK_REACH5)
         w1 = torch.zeros(E, dtype=torch.int32, device='cuda')
@@ -463,3 +470,25 @@ def test_c4_chain_pipelined_matches_chain_kernel_and_oracle(engine0, oracle_lib)
     sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
     cref, _, _ = cpu_run(oracle_lib, sub, out_reaches=pr['out_reaches'], n_threads=2)
     assert helpers.max_rel_err(out.cpu().numpy()[..., pick], cref, floor=FLOOR) < 1e-7
+
+
+@pytest.mark.parametrize('name', ['tarland_1981_2010_dynamic', 'confluence3_nc_2004'])
+def test_fp32_stage_mode(engine0, name):
+    """BASELINE config C5's arithmetic: the Runge-Kutta stages in fp32, the four daily integrals (Qr, Msus/TDP/PP
+    kg/day), the soil-P update and everything carried from day to day outside the stages in fp64.  Tolerance: 5e-4
+    relative on every reach output against the reference at rtol=atol=1e-12, with rtol 1e-5 / atol 1e-7 -- the same
+    error the fp64 scheme has at that tolerance (both asserted), i.e. the precision of the stages is not what limits
+    it.  fp32 cannot resolve rtol below ~3e-6; this mode is for screening ensembles, not for parity."""
+    solver = dict(rtol=1e-5, atol=1e-7)
+    gold = helpers.golden_tables(name, 'tight')
+    worst = {}
+    for integ in ('cashkarp_aug_f32', 'cashkarp_aug'):
+        m = helpers.marshal_scenario(name, E=2, solver=dict(solver, integrator=integ))
+        got, status, stats = gpu_run(engine0, m)
+        assert status.max() == 0
+        assert np.array_equal(got[..., 0], got[..., 1])
+        worst[integ] = max(helpers.max_rel_err(got[marshal.OUT_COLUMNS.index(c), :, j, 0], gold['R'][sc][c].values, floor=1e-300)
+                           for j, sc in enumerate(m['scs']) for c in REACH_COLS)
+        worst[integ + '_rhs'] = stats['rhs_evals']
+    assert worst['cashkarp_aug_f32'] < 5e-4 and worst['cashkarp_aug'] < 5e-4, worst
+    assert abs(worst['cashkarp_aug_f32_rhs'] - worst['cashkarp_aug_rhs']) < 0.02 * worst['cashkarp_aug_rhs'], worst
