@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 9
+#define SIMPLYP_ABI_VERSION 10
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -233,6 +233,60 @@ void* simplyp_device_alloc(simplyp_ctx* ctx, int64_t bytes);
 void  simplyp_device_free(simplyp_ctx* ctx, void* p);
 int   simplyp_memcpy_h2d(simplyp_ctx* ctx, void* dst, const void* src, int64_t bytes);
 int   simplyp_memcpy_d2h(simplyp_ctx* ctx, void* dst, const void* src, int64_t bytes);
+
+/* ---- goodness of fit per member (the reference's goodness_of_fit_stats, visualise_results.py:387-474, for a whole
+ * ensemble on the device) ------------------------------------------------------------ */
+enum {  /* variables, in the order of stats_var_li (visualise_results.py:400); simulated series = df_R columns
+           Q_cumecs, SS_mgl, TDP_mgl, PP_mgl, TP_mgl, SRP_mgl (:413-414; model.py:784-793, :831-847) */
+    SIMPLYP_GOF_Q = 0, SIMPLYP_GOF_SS, SIMPLYP_GOF_TDP, SIMPLYP_GOF_PP, SIMPLYP_GOF_TP, SIMPLYP_GOF_SRP,
+    SIMPLYP_N_GOF_VARS
+};
+enum {  /* rows of `gof`: the reference's table columns (:460-461) except Spearman's r (a rank statistic: host only),
+           plus the two sums the reference's Gaussian likelihood with sigma = m*sim needs
+           (Development/2016/MCMC.ipynb cell 6):
+           loglik(m) = -n/2 ln(2 pi) - n ln m - SUM_LOG_SIM - SUM_RELSQ / (2 m^2)                               */
+    SIMPLYP_GOFSTAT_N_OBS = 0,    /* non-null observations of the variable in the run period (:428)             */
+    SIMPLYP_GOFSTAT_NSE,          /* 1 - sum (obs-sim)^2 / sum (obs-mean obs)^2                         (:441)  */
+    SIMPLYP_GOFSTAT_LOG_NSE,      /* the same on natural logs                                            (:442)  */
+    SIMPLYP_GOFSTAT_R2,           /* squared Pearson correlation                                         (:446)  */
+    SIMPLYP_GOFSTAT_PBIAS,        /* 100 sum (sim-obs) / sum obs                                         (:448)  */
+    SIMPLYP_GOFSTAT_NRMSD,        /* 100 mean |sim-obs| / std(obs), ddof 0                               (:449)  */
+    SIMPLYP_GOFSTAT_SUM_LOG_SIM,  /* sum ln sim over the paired days                                             */
+    SIMPLYP_GOFSTAT_SUM_RELSQ,    /* sum (obs/sim - 1)^2 over the paired days                                    */
+    SIMPLYP_N_GOF_STATS
+};
+
+typedef struct {
+    double  kernel_ms;        /* both kernels, HIP events on the context's stream                                */
+    int64_t bytes_read;       /* algorithmic bytes: 8 per member and discharge day + 32 per member and chemistry day */
+    int32_t n_q_days;         /* discharge-observation days summed over the output reaches                       */
+    int32_t n_chem_days;      /* days with any chemistry observation, summed over the output reaches             */
+    int32_t n_chunks_q;       /* slices the discharge-day lists were cut into                                    */
+    int32_t n_chunks_chem;    /* slices the chemistry-day lists were cut into                                    */
+} simplyp_gof_info;
+
+/*
+ * simplyp_gof -- statistics of every member's simulated series against shared observations, from the daily table a
+ * previous simplyp_run left on the device.  Variables with 10 or fewer observations get NaN rows (the reference drops
+ * them, :430, :453); a day is used when the observation and the simulated value are both non-NaN (:436).
+ *
+ *   dims            E, S, D as in the run (n_forcing_sets ignored)
+ *   out_mask, out_reaches, n_out_reaches   as passed to simplyp_run; the mask must contain Qr, Msus_kg/day,
+ *                   TDP_kg/day and PP_kg/day, and the run must have written daily rows (opts.n_periods == 0)
+ *   out             device  [popcount(out_mask)][D][n_out_reaches][E]
+ *   member_of_slot  device  [E] or NULL (columns of `out` are in member order)
+ *   f_tdp           device  [E]: p['f_TDP'] of each member (SRP = f_TDP * TDP, model.py:844); not a run parameter
+ *   reach_params    device  as in the run (row SIMPLYP_PR_A_CATCH is read)
+ *   obs             HOST    [n_out_reaches][SIMPLYP_N_GOF_VARS][D], NaN = no observation that day
+ *   gof             device  [SIMPLYP_N_GOF_STATS][SIMPLYP_N_GOF_VARS][n_out_reaches][E], member order
+ *   info            host    may be NULL
+ * Synchronous.
+ */
+int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                const int32_t* out_reaches, int32_t n_out_reaches,
+                const double* out, const int32_t* member_of_slot,
+                const double* f_tdp, const double* reach_params,
+                const double* obs, double* gof, simplyp_gof_info* info);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
 
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1
@@ -36,6 +36,19 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}
+
+
+class GofInfo(C.Structure):
+    """simplyp_gof_info of include/simplyp.h."""
+    _fields_ = [('kernel_ms', C.c_double), ('bytes_read', C.c_int64), ('n_q_days', C.c_int32), ('n_chem_days', C.c_int32),
+                ('n_chunks_q', C.c_int32), ('n_chunks_chem', C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+GOF_VARS = ['Q', 'SS', 'TDP', 'PP', 'TP', 'SRP']                                      # SIMPLYP_GOF_*
+GOF_STATS = ['N obs', 'NSE', 'log NSE', 'r2', 'Bias (%)', 'nRMSD (%)', 'sum_log_sim', 'sum_relsq']   # SIMPLYP_GOFSTAT_*
 
 
 # Solver settings used when the caller does not choose: Cash-Karp 5(4) with per-thread step

@@ -7,12 +7,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <new>
 #include <numeric>
 #include <string>
 #include <vector>
 
 #include "simplyp_kernels.hip.h"
+#include "simplyp_gof.hip.h"
 
 namespace {
 
@@ -35,6 +37,8 @@ struct simplyp_ctx {
     DeviceBuf counters;       // 4 x uint64
     DeviceBuf balance;        // [E] uint32 pilot counts + [E] int32 permutation
     DeviceBuf sorted_params;  // slot-ordered copies of member_params, reach_params, forcing_of_member
+    DeviceBuf gof_lists;      // goodness-of-fit day lists, observations, shifts (simplyp_gof)
+    DeviceBuf gof_partial;    // [n_chunks][R][78][E] partial sums
     DeviceBuf queue;          // ticket, error, done[n_groups] (uint32) | ckpt[CKPT_N][E] (double)
     int queued = 0;           // last run used the task-queue kernel
     int n_simd_slots = 1024;  // CUs x 4 SIMDs: wave slots at one resident wave per SIMD
@@ -272,6 +276,8 @@ void simplyp_ctx_destroy(simplyp_ctx* ctx)
     if (ctx->balance.ptr) (void)hipFree(ctx->balance.ptr);
     if (ctx->sorted_params.ptr) (void)hipFree(ctx->sorted_params.ptr);
     if (ctx->queue.ptr) (void)hipFree(ctx->queue.ptr);
+    if (ctx->gof_lists.ptr) (void)hipFree(ctx->gof_lists.ptr);
+    if (ctx->gof_partial.ptr) (void)hipFree(ctx->gof_partial.ptr);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
@@ -632,6 +638,154 @@ int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* 
                                member_rhs_evals);
     if (rc != SIMPLYP_OK) return rc;
     return simplyp_sync(ctx, stats);
+}
+
+int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                const int32_t* out_reaches, int32_t n_out_reaches,
+                const double* out, const int32_t* member_of_slot,
+                const double* f_tdp, const double* reach_params,
+                const double* obs, double* gof, simplyp_gof_info* info)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is pending on this context; call simplyp_sync first");
+    if (!dims || dims->E <= 0 || dims->S <= 0 || dims->D <= 0) return fail(ctx, SIMPLYP_ERR_ARG, "bad dims");
+    if (!out || !f_tdp || !reach_params || !obs || !gof) return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
+    const uint32_t need = (1u << SIMPLYP_OUT_QR) | (1u << SIMPLYP_OUT_MSUS_FLUX) | (1u << SIMPLYP_OUT_TDP_FLUX) |
+                          (1u << SIMPLYP_OUT_PP_FLUX);
+    if ((out_mask & need) != need || (out_mask & ~SIMPLYP_MASK_ALL) != 0u)
+        return fail(ctx, SIMPLYP_ERR_ARG, "out_mask must contain Qr, Msus_kg/day, TDP_kg/day and PP_kg/day");
+    const int E = dims->E, S = dims->S, D = dims->D;
+    const int R = out_reaches ? n_out_reaches : S;
+    if (R <= 0 || R > S) return fail(ctx, SIMPLYP_ERR_ARG, "bad n_out_reaches");
+    std::vector<int32_t> reach_of(R);
+    for (int r = 0; r < R; ++r) {
+        reach_of[r] = out_reaches ? out_reaches[r] : r;
+        if (reach_of[r] < 0 || reach_of[r] >= S) return fail(ctx, SIMPLYP_ERR_ARG, "out_reaches[%d] out of range", r);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // Observation side, shared by all members: counts, conditioning shifts, compact day lists.
+    constexpr int NV = SIMPLYP_N_GOF_VARS;
+    std::vector<double> n_obs((size_t)R * NV, 0.0), shift((size_t)R * 12, 0.0);
+    std::vector<int32_t> q_ptr(R + 1, 0), c_ptr(R + 1, 0), q_day, c_day;
+    std::vector<double> q_obs, c_obs;
+    const double nan = std::nan("");
+    for (int r = 0; r < R; ++r) {
+        const double* ob = obs + (size_t)r * NV * D;
+        bool use[NV];
+        for (int v = 0; v < NV; ++v) {
+            double n = 0.0, so = 0.0, slo = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double o = ob[(size_t)v * D + d];
+                if (o == o) { n += 1.0; so += o; slo += std::log(o); }
+            }
+            use[v] = n > 10.0;                                   // visualise_results.py:430
+            n_obs[(size_t)r * NV + v] = n;
+            shift[(size_t)r * 12 + v] = use[v] ? so / n : 0.0;
+            // the log shift is only a conditioning constant: keep it finite when an observation is <= 0
+            const double ml = use[v] ? slo / n : 0.0;
+            shift[(size_t)r * 12 + 6 + v] = std::isfinite(ml) ? ml : 0.0;
+        }
+        for (int d = 0; d < D; ++d) {
+            const double q = ob[d];
+            if (use[0] && q == q) { q_day.push_back(d); q_obs.push_back(q); q_obs.push_back(std::log(q)); }
+            bool any = false;
+            double row[10];
+            for (int v = 1; v < NV; ++v) {
+                const double o = ob[(size_t)v * D + d];
+                const bool have = use[v] && o == o;
+                row[v - 1] = have ? o : nan;
+                row[v + 4] = have ? std::log(o) : nan;
+                any = any || have;
+            }
+            if (any) { c_day.push_back(d); c_obs.insert(c_obs.end(), row, row + 10); }
+        }
+        q_ptr[r + 1] = (int32_t)q_day.size();
+        c_ptr[r + 1] = (int32_t)c_day.size();
+    }
+
+    // column slots inside `out`
+    simplyp::GofArgs g{};
+    const int want[4] = {SIMPLYP_OUT_QR, SIMPLYP_OUT_MSUS_FLUX, SIMPLYP_OUT_TDP_FLUX, SIMPLYP_OUT_PP_FLUX};
+    for (int i = 0; i < 4; ++i) g.col[i] = popcount32(out_mask & ((1u << want[i]) - 1u));
+
+    const int groups = (E + simplyp::WAVE - 1) / simplyp::WAVE;
+    // Slices per day list.  All waves of a launch take the same time, so what matters is how many rounds the chip needs:
+    // pick the slice count with the fewest (rounds / slices), the smallest one within 3 % of the best (every slice costs a
+    // row of partial sums), and keep at least 32 days per slice.
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    auto pick_chunks = [&](const void* kernel, size_t list_len) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, simplyp::WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        const double cap = (double)per_cu * prop.multiProcessorCount;
+        const long long waves1 = (long long)groups * R;
+        const int n_max = (int)std::max<long long>(1, std::min<long long>(64, (long long)(list_len / (size_t)R) / 32));
+        int best = 1;
+        double best_cost = 1e300;
+        for (int n = 1; n <= n_max; ++n) {
+            const double cost = std::ceil((double)waves1 * n / cap) / n;
+            if (cost < best_cost * 0.97) { best = n; best_cost = cost; }
+        }
+        return best;
+    };
+    const int n_chunks_q = pick_chunks((const void*)simplyp::simplyp_gof_partial_kernel<0>, q_day.size());
+    const int n_chunks_c = pick_chunks((const void*)simplyp::simplyp_gof_partial_kernel<1>, c_day.size());
+    const int n_chunks = std::max(n_chunks_q, n_chunks_c);
+
+    // one upload: int32 block then double block
+    std::vector<int32_t> ints;
+    auto put_i = [&](const std::vector<int32_t>& v) { size_t at = ints.size(); ints.insert(ints.end(), v.begin(), v.end()); return at; };
+    const size_t o_reach = put_i(reach_of), o_qp = put_i(q_ptr), o_cp = put_i(c_ptr), o_qd = put_i(q_day), o_cd = put_i(c_day);
+    if (ints.size() & 1) ints.push_back(0);
+    std::vector<double> dbl;
+    auto put_d = [&](const std::vector<double>& v) { size_t at = dbl.size(); dbl.insert(dbl.end(), v.begin(), v.end()); return at; };
+    const size_t o_qo = put_d(q_obs), o_co = put_d(c_obs), o_sh = put_d(shift), o_n = put_d(n_obs);
+    const size_t ibytes = ints.size() * sizeof(int32_t), dbytes = dbl.size() * sizeof(double);
+    if (int rc = ensure(ctx, ctx->gof_lists, ibytes + dbytes)) return rc;
+    const size_t pbytes = (size_t)n_chunks * R * (NV * simplyp::GOF_NACC) * E * sizeof(double);
+    if (int rc = ensure(ctx, ctx->gof_partial, pbytes)) return rc;
+    char* base = (char*)ctx->gof_lists.ptr;
+    HIP_TRY(ctx, hipMemcpyAsync(base, ints.data(), ibytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(base + ibytes, dbl.data(), dbytes, hipMemcpyHostToDevice, ctx->stream));
+    // the host vectors must outlive the copies: pageable memory is staged before the call returns, and the
+    // stream is synchronised below in any case
+    const int32_t* di = (const int32_t*)base;
+    const double* dd = (const double*)(base + ibytes);
+    g.E = E; g.R = R; g.D = D;
+    g.out = out;
+    g.col_stride = (long long)D * R * E;
+    g.member_of_slot = member_of_slot;
+    g.f_tdp = f_tdp;
+    g.a_catch = reach_params + (size_t)SIMPLYP_PR_A_CATCH * S * E;
+    g.reach_of = di + o_reach; g.q_ptr = di + o_qp; g.c_ptr = di + o_cp; g.q_day = di + o_qd; g.c_day = di + o_cd;
+    g.q_obs = dd + o_qo; g.c_obs = dd + o_co; g.shift = dd + o_sh; g.n_obs = dd + o_n;
+    g.n_chunks_q = n_chunks_q;
+    g.n_chunks_c = n_chunks_c;
+    g.partial = (double*)ctx->gof_partial.ptr;
+    g.gof = gof;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    hipLaunchKernelGGL(simplyp::simplyp_gof_partial_kernel<0>, dim3(groups, n_chunks_q, R), dim3(simplyp::WAVE), 0, ctx->stream, g);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(simplyp::simplyp_gof_partial_kernel<1>, dim3(groups, n_chunks_c, R), dim3(simplyp::WAVE), 0, ctx->stream, g);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(simplyp::simplyp_gof_finish_kernel, dim3(groups, R, NV), dim3(simplyp::WAVE), 0, ctx->stream, g);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (info) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+        memset(info, 0, sizeof(*info));
+        info->kernel_ms = ms;
+        info->n_q_days = (int32_t)q_day.size();
+        info->n_chem_days = (int32_t)c_day.size();
+        info->bytes_read = ((int64_t)q_day.size() * 8 + (int64_t)c_day.size() * 32) * E;
+        info->n_chunks_q = n_chunks_q;
+        info->n_chunks_chem = n_chunks_c;
+    }
+    return SIMPLYP_OK;
 }
 
 void* simplyp_host_alloc(int64_t bytes)

@@ -25,7 +25,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 ABI_SYMBOLS = ['simplyp_abi_version', 'simplyp_device_count', 'simplyp_ctx_create', 'simplyp_ctx_destroy',
                'simplyp_last_error', 'simplyp_ctx_set_stream', 'simplyp_out_bytes', 'simplyp_run',
                'simplyp_run_async', 'simplyp_sync', 'simplyp_plan', 'simplyp_host_alloc', 'simplyp_host_free',
-               'simplyp_device_alloc', 'simplyp_device_free', 'simplyp_memcpy_h2d', 'simplyp_memcpy_d2h']
+               'simplyp_device_alloc', 'simplyp_device_free', 'simplyp_memcpy_h2d', 'simplyp_memcpy_d2h', 'simplyp_gof']
 
 _lib = None
 
@@ -85,6 +85,9 @@ def lib():
     L.simplyp_run_async.argtypes = run_args + [vp, vp]
     L.simplyp_sync.restype = C.c_int
     L.simplyp_sync.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.simplyp_gof.restype = C.c_int
+    L.simplyp_gof.argtypes = [vp, C.POINTER(abi.Dims), C.c_uint32, C.POINTER(C.c_int32), C.c_int32, dp, i32p, dp, dp,
+                              C.POINTER(C.c_double), dp, C.POINTER(abi.GofInfo)]
     L.simplyp_plan.restype = C.c_int
     L.simplyp_plan.argtypes = [C.c_int32] + [C.POINTER(C.c_int32)] * 8
     L.simplyp_host_alloc.restype = vp
@@ -237,6 +240,48 @@ class Engine(object):
         if member_of_slot is not None:
             sd['member_of_slot'] = member_of_slot
         return out, status, sd
+
+
+    def gof(self, out, out_mask, obs, f_tdp, reach_params, out_reaches=None, member_of_slot=None):
+        """Per-member goodness-of-fit statistics (the reference's ``goodness_of_fit_stats``,
+        visualise_results.py:387-474, without Spearman's r) of the daily table ``out`` of a previous ``run``.
+
+        out [n_cols,D,n_out_reaches,E] device tensor written with ``out_mask`` (must contain Qr and the three daily
+        fluxes); obs [n_out_reaches,6,D] host array, NaN = no observation (``visualise_results.observation_array``);
+        f_tdp [E] or scalar; reach_params [NP_R,S,E].  Returns (gof [n_stats,6,n_out_reaches,E] device tensor in member
+        order -- rows ``abi.GOF_STATS``, variables ``abi.GOF_VARS`` -- and an info dict)."""
+        torch = self.torch
+        L = lib()
+        rp = self.to_device(reach_params, torch.float64)
+        npr, S, E = rp.shape
+        ncols, D, n_or, E2 = out.shape
+        oreach = _i32(out_reaches)
+        if (E2 != E or ncols != bin(out_mask).count('1') or n_or != (S if oreach is None else len(oreach))
+                or out.dtype != torch.float64 or not out.is_contiguous()):
+            raise ValueError("out %s does not match out_mask / out_reaches / reach_params %s" % (tuple(out.shape), tuple(rp.shape)))
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        if obs.shape != (n_or, len(abi.GOF_VARS), D):
+            raise ValueError("obs must have shape %s, got %s" % ((n_or, len(abi.GOF_VARS), D), obs.shape))
+        ft = self.to_device(np.broadcast_to(np.asarray(f_tdp, dtype=np.float64), (E,)) if not torch.is_tensor(f_tdp) else f_tdp,
+                            torch.float64)
+        if tuple(ft.shape) != (E,):
+            raise ValueError("f_tdp must be a scalar or have one entry per member")
+        gof = torch.empty((len(abi.GOF_STATS), len(abi.GOF_VARS), n_or, E), dtype=torch.float64, device=self.tdev)
+        info = abi.GofInfo()
+        dims = abi.Dims(E, S, D, 1)
+        with torch.cuda.device(self.tdev):
+            if self._use_torch_stream:
+                self._check(L.simplyp_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                            'simplyp_ctx_set_stream')
+            else:
+                torch.cuda.current_stream().synchronize()
+            rc = L.simplyp_gof(self._h, C.byref(dims), int(out_mask),
+                               None if oreach is None else oreach.ctypes.data_as(C.POINTER(C.c_int32)), n_or,
+                               out.data_ptr(), None if member_of_slot is None else member_of_slot.data_ptr(),
+                               ft.data_ptr(), rp.data_ptr(), obs.ctypes.data_as(C.POINTER(C.c_double)), gof.data_ptr(),
+                               C.byref(info))
+        self._check(rc, 'simplyp_gof')
+        return gof, info.as_dict()
 
 
 _engines = {}

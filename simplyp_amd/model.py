@@ -230,7 +230,7 @@ def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len
 
 def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
                           outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True,
-                          reduce=None):
+                          reduce=None, obs_dict=None, keep_daily=True):
     """Run an ensemble of parameter sets through the engine in one call.
 
     ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
@@ -240,6 +240,13 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     sub-catchment ids to return (default all).  ``reduce``: None for daily rows, ``'annual'`` for one row
     per calendar year holding the sum of that year's daily values (e.g. annual fluxes), or an int array
     [D] of period indices; the periods are returned under ``'periods'``.
+    ``obs_dict``: observations as returned by ``read_input_data`` (dict SC -> DataFrame with columns among
+    Q, SS, TDP, PP, TP, SRP): every member's goodness-of-fit table (the reference's ``goodness_of_fit_stats``,
+    visualise_results.py:387-474, minus Spearman's r, plus the two sums of its Gaussian likelihood) is reduced on the
+    device from the daily series and returned under ``'gof'`` = dict(stats, variables, data[n_stats, 6, n_reaches, E],
+    info); needs daily rows (``reduce=None``); the four flux columns are added to ``outputs`` when missing.  ``SRP``
+    uses ``p['f_TDP']`` or ``overrides['f_TDP']`` (array[E]).  ``keep_daily=False`` drops the daily table once the
+    statistics exist (``data`` is None): the 44 GB of a 100 000-member run never leave the device.
 
     Returns ``dict(columns, reaches, data[n_cols, D or n_periods, n_reaches, E], status[E], stats)``; ``data``
     and ``status`` are numpy arrays, or device tensors when ``to_host`` is False.
@@ -250,8 +257,10 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     marshal.prologue(p_SU, p_LU, p_SC, p)
     scs = marshal.sc_list(p)
     up_ptr, up_idx, _ = marshal.topology(p_struc, p)
+    overrides = dict(overrides or {})
+    f_tdp = overrides.pop('f_TDP', None)
     m_over, r_over = marshal.split_member_reach_overrides(overrides)
-    sizes = {np.asarray(v).shape[-1] for v in list(m_over.values()) + list(r_over.values()) if np.ndim(v) > 0}
+    sizes = {np.asarray(v).shape[-1] for v in list(m_over.values()) + list(r_over.values()) + [f_tdp] if v is not None and np.ndim(v) > 0}
     if n_members is None:
         if len(sizes) != 1:
             raise ValueError("cannot infer the ensemble size: give n_members or override arrays of one length")
@@ -261,6 +270,10 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     rp = marshal.reach_params(p_SC, p, E, r_over)
     forcing, doy = marshal.forcing_arrays(met_df)
     cols = list(outputs) if outputs is not None else list(marshal.REACH5_COLUMNS)
+    if obs_dict is not None:
+        if reduce is not None:
+            raise ValueError("goodness of fit needs the daily series: obs_dict cannot be combined with reduce")
+        cols += [c for c in ('Qr', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day') if c not in cols]
     mask = marshal.mask_of_columns(cols)
     period_of_day, periods = None, None
     if reduce is not None:
@@ -280,10 +293,21 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     oreach = None if out_reaches is None else [scs.index(int(r)) for r in out_reaches]
 
     eng = engine.get_engine(device)
-    out_d, status_d, stats = eng.run(forcing, doy, mp, rp, up_ptr, up_idx, opts, out_reaches=oreach,
+    rp_d = eng.to_device(rp)
+    out_d, status_d, stats = eng.run(forcing, doy, mp, rp_d, up_ptr, up_idx, opts, out_reaches=oreach,
                                      period_of_day=period_of_day)
     marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)
-    return dict(columns=marshal.columns_of_mask(mask), reaches=(scs if out_reaches is None else list(out_reaches)),
-                periods=periods,
-                data=out_d.cpu().numpy() if to_host else out_d,
-                status=status_d.cpu().numpy() if to_host else status_d, stats=stats)
+    reaches = scs if out_reaches is None else list(out_reaches)
+    res = dict(columns=marshal.columns_of_mask(mask), reaches=reaches, periods=periods, stats=stats,
+               status=status_d.cpu().numpy() if to_host else status_d)
+    if obs_dict is not None:
+        from . import visualise_results as vr
+        obs = vr.observation_array(obs_dict, reaches, met_df.index)
+        gof_d, info = eng.gof(out_d, mask, obs, p['f_TDP'] if f_tdp is None else f_tdp, rp_d, out_reaches=oreach,
+                              member_of_slot=stats.get('member_of_slot') if opts.out_slot_order else None)
+        res['gof'] = dict(stats=list(abi.GOF_STATS), variables=list(abi.GOF_VARS), info=info,
+                          data=gof_d.cpu().numpy() if to_host else gof_d)
+        if not keep_daily:
+            out_d = None
+    res['data'] = None if out_d is None else (out_d.cpu().numpy() if to_host else out_d)
+    return res

@@ -86,3 +86,29 @@ def marshal_scenario(name, E=1, out_mask=None, solver=None):
                          out_mask=marshal.MASK_ALL if out_mask is None else out_mask)
     return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx, opts=opts,
                 scs=scs, met=met)
+
+
+def observations(st_dt, end_dt):
+    """obs_dict of the shipped Tarland observation workbooks (tests/golden/reference_data), truncated to the run
+    period the way the reference's read_input_data does (inputs.py:118-152)."""
+    from simplyp_amd import xlsx
+    df_li = []
+    for f in ('Coull_DailyMeanQ.xlsx', 'Coull_ChemObs.xlsx'):
+        wb = xlsx.Workbook(os.path.join(GOLDEN, 'reference_data', f))
+        df = xlsx.read_excel(wb, '1', index_col=0)
+        df.index = pd.to_datetime(df.index)
+        df_li.append(df.sort_index().truncate(before=st_dt, after=end_dt))
+    return {1: pd.concat(df_li, axis=1)}
+
+
+def gof_golden():
+    with open(os.path.join(GOLDEN, 'gof_golden.json')) as fh:
+        return json.load(fh)
+
+
+def gof_case_factors(index):
+    """The deterministic multiplicative perturbations of tests/golden/make_gof_golden.py (case -> Q and concentration factors)."""
+    t = np.arange(len(index)) / 365.25
+    return {'base': dict(Q=1.0, C=1.0),
+            'wet': dict(Q=1.25 + 0.1 * np.sin(2 * np.pi * t), C=0.8),
+            'dry': dict(Q=0.7, C=1.4 + 0.3 * np.cos(2 * np.pi * t / 3.0))}

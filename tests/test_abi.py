@@ -34,12 +34,17 @@ def test_enums_match_python_tables():
     out = re.search(r'enum \{\s*SIMPLYP_OUT_VSA = 0(.*?)SIMPLYP_N_OUT', txt, re.S).group(0)
     assert len(re.findall(r'SIMPLYP_OUT_[A-Z0-9_]+', out)) == marshal.N_OUT == 25
     assert marshal.MASK_REACH5 == (1 << 3) | (1 << 5) | (1 << 7) | (1 << 9) | (1 << 11)
+    gv = re.search(r'SIMPLYP_GOF_Q = 0(.*?)SIMPLYP_N_GOF_VARS', txt, re.S).group(0)
+    assert [n.lower() for n in re.findall(r'SIMPLYP_GOF_([A-Z]+)', gv)] == [v.lower() for v in abi.GOF_VARS]
+    gs = re.search(r'SIMPLYP_GOFSTAT_N_OBS = 0(.*?)SIMPLYP_N_GOF_STATS', txt, re.S).group(0)
+    assert len(re.findall(r'SIMPLYP_GOFSTAT_[A-Z0-9_]+', gs)) == len(abi.GOF_STATS) == 8
 
 
 def test_struct_layouts(tmp_path):
     """ctypes mirrors vs the C compiler's view of include/simplyp.h (sizeof / offsetof of every field)."""
     import subprocess
-    structs = {'simplyp_dims': abi.Dims, 'simplyp_opts': abi.Opts, 'simplyp_stats': abi.Stats}
+    structs = {'simplyp_dims': abi.Dims, 'simplyp_opts': abi.Opts, 'simplyp_stats': abi.Stats,
+               'simplyp_gof_info': abi.GofInfo}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HEADER, 'int main(void){']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
