@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 10
+#define SIMPLYP_ABI_VERSION 11
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -47,6 +47,7 @@ enum {
     SIMPLYP_PM_P_NETINPUT_A, SIMPLYP_PM_P_NETINPUT_NC, SIMPLYP_PM_EPC0_INIT_A, SIMPLYP_PM_EPC0_INIT_S,
     SIMPLYP_PM_C_COVER_A, SIMPLYP_PM_C_COVER_S, SIMPLYP_PM_C_COVER_IG,
     SIMPLYP_PM_C_MEAS_A, SIMPLYP_PM_C_MEAS_S, SIMPLYP_PM_C_MEAS_IG,
+    SIMPLYP_PM_F_DDSM, SIMPLYP_PM_D_SNOW_0,   /* snow module (inputs.py:159-210); read only when opts.snow = 1 */
     SIMPLYP_NP_M
 };
 
@@ -131,6 +132,14 @@ typedef struct {
                                 Results are unchanged bit for bit.                                              */
     int32_t  n_periods;      /* time-reduced output: 0 = one output row per day; > 0 = `out` has n_periods rows per column,
                                 row p = sum over the days d with period_of_day[d] == p (e.g. calendar years) */
+    int32_t  snow;           /* 0: forcing row 0 is the hydrological input P as the reference's snow_hydrol_inputs left it in
+                                met_df['P'] (2 rows per set: P, PET).  1: the snow module runs inside the kernel, per member:
+                                forcing has 3 rows per set -- Precipitation, PET, T_air (the met file's columns) -- and every
+                                member accumulates / melts its own snow pack with its SIMPLYP_PM_F_DDSM and
+                                SIMPLYP_PM_D_SNOW_0 (inputs.py:183-208), so an ensemble can perturb the snow parameters
+                                without one forcing set per member.  Same arithmetic, same order: P is bit-identical
+                                to the host function's.                                                          */
+    int32_t  reserved;
 } simplyp_opts;
 
 typedef struct {
@@ -170,7 +179,8 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
  * Replaces model.py:365-724 for the whole ensemble in one call.
  *
  *   forcing           device  [n_forcing_sets][2][D]   row 0 = P (met_df['P'], model.py:497),
- *                                                      row 1 = PET (model.py:498)
+ *                                                      row 1 = PET (model.py:498);
+ *                             with opts.snow = 1: [n_forcing_sets][3][D], rows Precipitation, PET, T_air
  *   doy               device  [D]        day of year 1..366 (met_df.index[idx].dayofyear, :550)
  *   period_of_day     device  [D] int32 in [0, opts.n_periods), or NULL when opts.n_periods == 0
  *   forcing_of_member device  [E] or NULL (all members use set 0)

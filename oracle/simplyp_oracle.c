@@ -389,8 +389,9 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
                        int n_out_reaches, int n_integ, double* out, int32_t* status, integ_stats* st)
 {
     const int E = dims->E, S = dims->S, D = dims->D;
-    const double* Pser = forcing + (size_t)(fom ? fom[e] : 0) * 2 * D;
+    const double* Pser = forcing + (size_t)(fom ? fom[e] : 0) * (o->snow ? 3 : 2) * D;   /* Precipitation when o->snow */
     const double* Eser = Pser + D;
+    const double* Tser = Eser + D;                                                        /* T_air (o->snow only) */
     /* daily series of every reach of this member that a downstream reach may read (:524-528) */
     double* route = (double*)malloc(sizeof(double) * 4 * (size_t)S * D);
     int col_of[SIMPLYP_N_OUT], ncols = 0;
@@ -449,9 +450,20 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
         const double S_reach = RP(S_REACH, s), f_spr = RP(F_SPR, s);
 
         double h_carry = o->step_len / (o->substeps > 0 ? o->substeps : 1);
+        double D_snow = o->snow ? MP(D_SNOW_0) : 0.0;                                            /* inputs.py:198 */
 
         for (int idx = 0; idx < D; ++idx) {                                                      /* :491 */
             double P = Pser[idx], Ev = Eser[idx];                                                /* :497-498 */
+            if (o->snow) {      /* snow_hydrol_inputs, inputs.py:183-208, for this member and day */
+                const double T_air = Tser[idx];
+                const double P_snow = (T_air < 0.0) ? P : 0.0;                                   /* :183-184 */
+                const double P_rain = P - P_snow;                                                /* :187 */
+                double P_melt = MP(F_DDSM) * (T_air - 0);                                        /* :190 */
+                if (P_melt < 0.0) P_melt = 0.0;                                                  /* :191 */
+                P_melt = (D_snow < P_melt) ? D_snow : P_melt;                                    /* :199, :204 */
+                D_snow = D_snow + P_snow - P_melt;                                               /* :200, :205 */
+                P = P_rain + P_melt;                                                             /* :208 */
+            }
             double Qq_i = f_quick * P;                                                           /* :501 */
 
             double Qr_US_i = 0.0, Msus_US_i = 0.0, TDPr_US_i = 0.0, PPr_US_i = 0.0;              /* :544 */

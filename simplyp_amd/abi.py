@@ -2,7 +2,7 @@
 
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1
@@ -26,7 +26,7 @@ class Opts(C.Structure):
                 ('run_mode_cal', C.c_int32), ('sc_qr0', C.c_int32), ('out_mask', C.c_uint32),
                 ('step_len', C.c_double), ('project_vr', C.c_int32), ('balance', C.c_int32),
                 ('balance_pilot_days', C.c_int32), ('out_slot_order', C.c_int32),
-                ('time_chunk_days', C.c_int32), ('n_periods', C.c_int32)]
+                ('time_chunk_days', C.c_int32), ('n_periods', C.c_int32), ('snow', C.c_int32), ('reserved', C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -59,7 +59,7 @@ DEFAULT_SOLVER = dict(integrator='cashkarp_aug', substeps=8, rtol=1e-8, atol=1e-
 
 
 def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=True, sc_qr0=0,
-              out_mask=(1 << 25) - 1, step_len=1.0, n_periods=0):
+              out_mask=(1 << 25) - 1, step_len=1.0, n_periods=0, snow=False):
     s = dict(DEFAULT_SOLVER)
     s.update(solver or {})
     integ = s['integrator']
@@ -83,4 +83,5 @@ def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=
     o.out_mask = int(out_mask)
     o.step_len = float(step_len)
     o.n_periods = int(n_periods)
+    o.snow = 1 if snow else 0
     return o

@@ -405,6 +405,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     a.params_by_slot = 0;
     a.member_rhs = member_rhs_evals;
     const unsigned gx = (unsigned)((E + simplyp::WAVE - 1) / simplyp::WAVE);
+    const bool snow = opts->snow != 0;
     auto launch_all = [&](const simplyp::KernelArgs& base) -> int {
         simplyp::KernelArgs k = base;
         for (size_t l = 0; l < sch.launches.size(); ++l) {
@@ -412,14 +413,16 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
             k.chain_reach = dsched + off_creach[l];
             const unsigned n_chains = (unsigned)sch.launches[l].chain_ptr.size() - 1u;
             dim3 grid(gx, n_chains, 1), block(simplyp::WAVE, 1, 1);
-            if (opts->integrator == SIMPLYP_INTEG_RK4)
-                hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_RK4>, grid, block, 0, ctx->stream, k);
-            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP)
-                hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP>, grid, block, 0, ctx->stream, k);
-            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32)
-                hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP_AUG_F32>, grid, block, 0, ctx->stream, k);
-            else
-                hipLaunchKernelGGL(simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP_AUG>, grid, block, 0, ctx->stream, k);
+#define SIMPLYP_LAUNCH_CHAIN(INTEG)                                                                                   \
+    do {                                                                                                              \
+        if (snow) hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, true>), grid, block, 0, ctx->stream, k);   \
+        else hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, false>), grid, block, 0, ctx->stream, k);       \
+    } while (0)
+            if (opts->integrator == SIMPLYP_INTEG_RK4) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_RK4);
+            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP);
+            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG_F32);
+            else SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG);
+#undef SIMPLYP_LAUNCH_CHAIN
             HIP_TRY(ctx, hipGetLastError());
         }
         return SIMPLYP_OK;
@@ -567,12 +570,15 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
             unsigned workers = (unsigned)std::min<long long>(n_tasks, ctx->n_simd_slots);
             if (const char* w_env = getenv("SIMPLYP_QUEUE_WORKERS")) workers = std::max(1u, std::min(workers, (unsigned)strtoul(w_env, nullptr, 10)));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
-            if (opts->integrator == SIMPLYP_INTEG_CASHKARP)
-                hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
-            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32)
-                hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG_F32>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
-            else
-                hipLaunchKernelGGL(simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG>, dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);
+#define SIMPLYP_LAUNCH_QUEUE(INTEG)                                                                                                       \
+    do {                                                                                                                                  \
+        if (snow) hipLaunchKernelGGL((simplyp::simplyp_queue_kernel<INTEG, true>), dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);  \
+        else hipLaunchKernelGGL((simplyp::simplyp_queue_kernel<INTEG, false>), dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);      \
+    } while (0)
+            if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP);
+            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG_F32);
+            else SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG);
+#undef SIMPLYP_LAUNCH_QUEUE
             HIP_TRY(ctx, hipGetLastError());
             if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] queue kernel launched: S=%d G=%d pairs=%zu chunk=%d ring=%d workers=%u max_polls=%u\n", S, G, pair_idx.size(), chunk_days, ring_chunks, workers, q.max_polls);
             ctx->queued = 1;

@@ -594,10 +594,10 @@ __device__ __forceinline__ void soil_p_update(double P_netInput, double A_catch,
 // Everything one lane does for one member over days [d_begin, d_end) of every reach of its chain.
 // `ckpt` ([CKPT_N][E], slot-major) carries a member's state across a time-chunk boundary for the queue
 // kernel (single-reach problems); the chain kernel passes nullptr and runs all days of every reach.
-constexpr int CKPT_N = 15;    // y[8], Plab_A, TDPs_A, Plab_NC, TDPs_NC, conc_A, conc_NC, h_carry
+constexpr int CKPT_N = 16;    // y[8], Plab_A, TDPs_A, Plab_NC, TDPs_NC, conc_A, conc_NC, h_carry, snow depth
 
-template <int INTEG>
-__device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, double* s_E, int* s_doy,
+template <int INTEG, bool SNOW>
+__device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, double* s_E, double* s_T, int* s_doy,
                                          const int lane, const int slot_raw, const int* reaches, const int n_reaches,
                                          const int d_begin, const int d_end, double* ckpt)
 {
@@ -617,8 +617,9 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
 
     const int set = a.forcing_of_member ? a.forcing_of_member[pe] : 0;
     const bool shared_forcing = (a.forcing_of_member == nullptr);
-    const double* Pser = a.forcing + (size_t)set * 2 * Dst;
+    const double* Pser = a.forcing + (size_t)set * (SNOW ? 3 : 2) * Dst;        // P, or Precipitation when SNOW
     const double* Eser = Pser + Dst;
+    const double* Tser = Eser + Dst;                                            // T_air (SNOW only)
 
     // ---- member constants (model.py:349-361, 377-390) ----
     const double fc = MPv(SIMPLYP_PM_FC), f_quick = MPv(SIMPLYP_PM_F_QUICK), alpha = MPv(SIMPLYP_PM_ALPHA);
@@ -674,12 +675,14 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
         double conc_A = TDPs_A / fc;                                                              // :438
         double conc_NC = TDPs_NC / fc;                                                            // :446 (VsA0 == VsS0)
         double h_carry = a.step_len / (double)(a.substeps > 0 ? a.substeps : 1);
+        double D_snow = SNOW ? MPv(SIMPLYP_PM_D_SNOW_0) : 0.0;                                    // inputs.py:198
         if (ckpt && d_begin > 0) {      // resume from the previous time chunk (written by whichever wave ran it)
             const double* k = ckpt + slot;
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = k[(size_t)i * E];
             Plab_A = k[(size_t)8 * E]; TDPs_A = k[(size_t)9 * E]; Plab_NC = k[(size_t)10 * E]; TDPs_NC = k[(size_t)11 * E];
             conc_A = k[(size_t)12 * E]; conc_NC = k[(size_t)13 * E]; h_carry = k[(size_t)14 * E];
+            if (SNOW) D_snow = k[(size_t)15 * E];
         }
 
         // per-reach pieces of the day constants
@@ -720,12 +723,24 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
             if (shared_forcing) {
                 __syncthreads();
                 for (int i = lane; i < nd; i += WAVE) { s_P[i] = Pser[d0 + i]; s_E[i] = Eser[d0 + i]; }
+                if (SNOW) for (int i = lane; i < nd; i += WAVE) s_T[i] = Tser[d0 + i];
                 if (a.dynamic_erod) for (int i = lane; i < nd; i += WAVE) s_doy[i] = a.doy[d0 + i];
                 __syncthreads();
             }
             for (int dd = 0; dd < nd; ++dd) {
                 const int d = d0 + dd;
-                const double P = shared_forcing ? s_P[dd] : Pser[d];                              // :497
+                double P = shared_forcing ? s_P[dd] : Pser[d];                                    // :497
+                if (SNOW) {
+                    // snow_hydrol_inputs (inputs.py:183-208) for this member: P so far is the day's precipitation
+                    const double T_air = shared_forcing ? s_T[dd] : Tser[d];
+                    const double P_snow = (T_air < 0.0) ? P : 0.0;                                // :183-184
+                    const double P_rain = P - P_snow;                                             // :187
+                    double P_melt = MPv(SIMPLYP_PM_F_DDSM) * (T_air - 0);                         // :190
+                    if (P_melt < 0.0) P_melt = 0.0;                                               // :191
+                    P_melt = (D_snow < P_melt) ? D_snow : P_melt;                                 // :199, :204 melt limited by depth
+                    D_snow = D_snow + P_snow - P_melt;                                            // :200, :205
+                    P = P_rain + P_melt;                                                          // :208
+                }
                 const double PET = shared_forcing ? s_E[dd] : Eser[d];                            // :498
                 const double Qq = f_quick * P;                                                    // :501
 
@@ -904,6 +919,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
             for (int i = 0; i < 8; ++i) k[(size_t)i * E] = y[i];
             k[(size_t)8 * E] = Plab_A; k[(size_t)9 * E] = TDPs_A; k[(size_t)10 * E] = Plab_NC; k[(size_t)11 * E] = TDPs_NC;
             k[(size_t)12 * E] = conc_A; k[(size_t)13 * E] = conc_NC; k[(size_t)14 * E] = h_carry;
+            if (SNOW) k[(size_t)15 * E] = D_snow;
         }
     }
 #undef MPv
@@ -924,14 +940,15 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
 }
 
 // fp64 schemes need ~500 registers for the Cash-Karp stages (one wave per SIMD); the fp32 scheme is asked to fit two
-template <int INTEG>
+template <int INTEG, bool SNOW>
 __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs a)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
+    __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
     const int c0 = a.chain_ptr[blockIdx.y], c1 = a.chain_ptr[blockIdx.y + 1];
-    run_slot<INTEG>(a, s_P, s_E, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+    run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -993,11 +1010,12 @@ __device__ __forceinline__ unsigned queue_take_ticket(const QueueArgs& q, int la
 
 // The persistent loop has a single exit, at its head, on a scalar: with `break`s in the body hipcc (ROCm 7.2)
 // structurised the ticket loop into a lane-masked inner loop that re-ran task 0 forever.
-template <int INTEG>
+template <int INTEG, bool SNOW>
 __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
+    __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
     const int lane = threadIdx.x;
     const unsigned G = (unsigned)q.n_groups;
@@ -1019,7 +1037,7 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int d_begin = c * q.chunk_days;
             const int d_end = min(a.D, d_begin + q.chunk_days);
-            run_slot<INTEG>(a, s_P, s_E, s_doy, lane, g * WAVE + lane, q.task_reach + pair, 1, d_begin, d_end,
+            run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, lane, g * WAVE + lane, q.task_reach + pair, 1, d_begin, d_end,
                             q.ckpt + (size_t)s * CKPT_N * (size_t)a.E);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -178,7 +178,7 @@ class Engine(object):
             out_reaches=None, out=None, member_rhs=None, member_of_slot=None, period_of_day=None):
         """Integrate every (member, reach) through all days on the device.
 
-        forcing [n_sets,2,D], doy [D], member_params [NP_M,E], reach_params [NP_R,S,E] may be numpy
+        forcing [n_sets,2,D] (rows P, PET; [n_sets,3,D] = Precipitation, PET, T_air with ``opts.snow``), doy [D], member_params [NP_M,E], reach_params [NP_R,S,E] may be numpy
         arrays or device tensors.  Returns (out [n_cols,D,n_out_reaches,E] device tensor,
         status [E] device tensor, stats dict).  ``member_rhs``: optional int32 device tensor [E] that
         receives the per-member count of right-hand-side evaluations.  With ``opts.out_slot_order`` the
@@ -199,7 +199,7 @@ class Engine(object):
         npm, E = mp.shape
         npr, S, E2 = rp.shape
         from . import marshal
-        if two != 2 or npm != marshal.NP_M or npr != marshal.NP_R or E2 != E or dy.shape[0] != D:
+        if two != (3 if opts.snow else 2) or npm != marshal.NP_M or npr != marshal.NP_R or E2 != E or dy.shape[0] != D:
             raise ValueError("inconsistent array shapes: forcing %s doy %s member_params %s reach_params %s"
                              % (tuple(f.shape), tuple(dy.shape), tuple(mp.shape), tuple(rp.shape)))
         up_ptr = _i32(up_ptr)

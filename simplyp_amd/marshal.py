@@ -24,6 +24,7 @@ PM_SPEC = [
     ('C_cover_A', ('LU', 'C_cover', 'A')), ('C_cover_S', ('LU', 'C_cover', 'S')), ('C_cover_IG', ('LU', 'C_cover', 'IG')),
     ('C_measures_A', ('LU', 'C_measures', 'A')), ('C_measures_S', ('LU', 'C_measures', 'S')),
     ('C_measures_IG', ('LU', 'C_measures', 'IG')),
+    ('f_DDSM', ('p', 'f_DDSM')), ('D_snow_0', ('p', 'D_snow_0')),      # snow module, read when opts.snow = 1
 ]
 PM_NAMES = [n for n, _ in PM_SPEC]
 NP_M = len(PM_NAMES)
@@ -168,9 +169,12 @@ def reach_params(p_SC, p, E=1, overrides=None):
     return out
 
 
-def forcing_arrays(met_df):
-    """([1, 2, D] fp64 with rows P, PET ; doy[D] int32) from the met dataframe (model.py:497-498, :550)."""
-    f = np.stack([met_df['P'].to_numpy(dtype=np.float64), met_df['PET'].to_numpy(dtype=np.float64)])[None]
+def forcing_arrays(met_df, snow=False):
+    """([1, 2, D] fp64 with rows P, PET ; doy[D] int32) from the met dataframe (model.py:497-498, :550).
+    ``snow=True``: [1, 3, D] with rows Precipitation, PET, T_air -- the raw met columns the in-kernel snow module
+    (opts.snow = 1; reference inputs.py:159-210) turns into each member's own P."""
+    rows = ['Precipitation', 'PET', 'T_air'] if snow else ['P', 'PET']
+    f = np.stack([met_df[c].to_numpy(dtype=np.float64) for c in rows])[None]
     doy = np.asarray(met_df.index.dayofyear, dtype=np.int32)
     return np.ascontiguousarray(f), np.ascontiguousarray(doy)
 

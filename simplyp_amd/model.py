@@ -126,14 +126,14 @@ def sum_to_waterbody(p_struc, n_SC, df_R_dict, f_TDP):
 # ------------------------------------------------------------------------------------------
 # the hot path
 
-def _engine_opts(p_SU, p, dynamic_options, step_len, solver, out_mask, n_periods=0):
+def _engine_opts(p_SU, p, dynamic_options, step_len, solver, out_mask, n_periods=0, snow=False):
     scs = marshal.sc_list(p)
     return abi.make_opts(solver,
                          dynamic_epc0=(dynamic_options['Dynamic_EPC0'] == 'y'),
                          dynamic_erod=(dynamic_options['Dynamic_erodibility'] == 'y'),
                          run_mode_cal=(p_SU.run_mode == 'cal'),
                          sc_qr0=scs.index(int(p['SC_Qr0'])),
-                         out_mask=out_mask, step_len=step_len, n_periods=n_periods)
+                         out_mask=out_mask, step_len=step_len, n_periods=n_periods, snow=snow)
 
 
 def _kf_last(p_SU, p_LU, p_SC, p):
@@ -230,7 +230,7 @@ def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len
 
 def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
                           outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True,
-                          reduce=None, obs_dict=None, keep_daily=True):
+                          reduce=None, obs_dict=None, keep_daily=True, snow_in_kernel=None):
     """Run an ensemble of parameter sets through the engine in one call.
 
     ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
@@ -240,6 +240,9 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     sub-catchment ids to return (default all).  ``reduce``: None for daily rows, ``'annual'`` for one row
     per calendar year holding the sum of that year's daily values (e.g. annual fluxes), or an int array
     [D] of period indices; the periods are returned under ``'periods'``.
+    ``snow_in_kernel``: run the degree-day snow module (reference ``snow_hydrol_inputs``, inputs.py:159-210) per member
+    inside the kernel from ``met_df['Precipitation']`` / ``['T_air']`` instead of taking ``met_df['P']``; default: on when
+    ``overrides`` perturbs ``f_DDSM`` or ``D_snow_0`` (with the workbook values the result is bit-identical either way).
     ``obs_dict``: observations as returned by ``read_input_data`` (dict SC -> DataFrame with columns among
     Q, SS, TDP, PP, TP, SRP): every member's goodness-of-fit table (the reference's ``goodness_of_fit_stats``,
     visualise_results.py:387-474, minus Spearman's r, plus the two sums of its Gaussian likelihood) is reduced on the
@@ -268,7 +271,11 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     E = int(n_members)
     mp = marshal.member_params(p, p_LU, E, m_over)
     rp = marshal.reach_params(p_SC, p, E, r_over)
-    forcing, doy = marshal.forcing_arrays(met_df)
+    if snow_in_kernel is None:
+        snow_in_kernel = 'f_DDSM' in m_over or 'D_snow_0' in m_over
+    if snow_in_kernel and not {'Precipitation', 'T_air'} <= set(met_df.columns):
+        raise ValueError("the in-kernel snow module needs met_df columns 'Precipitation' and 'T_air'")
+    forcing, doy = marshal.forcing_arrays(met_df, snow=snow_in_kernel)
     cols = list(outputs) if outputs is not None else list(marshal.REACH5_COLUMNS)
     if obs_dict is not None:
         if reduce is not None:
@@ -289,7 +296,7 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
             periods = np.arange(int(period_of_day.max()) + 1)
         period_of_day = np.ascontiguousarray(period_of_day, dtype=np.int32)
     opts = _engine_opts(p_SU, p, dynamic_options, step_len, solver, mask,
-                        n_periods=0 if periods is None else len(periods))
+                        n_periods=0 if periods is None else len(periods), snow=snow_in_kernel)
     oreach = None if out_reaches is None else [scs.index(int(r)) for r in out_reaches]
 
     eng = engine.get_engine(device)

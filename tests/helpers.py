@@ -71,7 +71,7 @@ def max_rel_err(a, b, floor=0.0):
     return float(np.nanmax(r)) if r.size else 0.0
 
 
-def marshal_scenario(name, E=1, out_mask=None, solver=None):
+def marshal_scenario(name, E=1, out_mask=None, solver=None, snow=False):
     """Arrays + opts for engine/oracle `run` from a golden scenario (base parameters replicated E times)."""
     from simplyp_amd import marshal, abi
     met, p_struc, p_SU, p_LU, p_SC, p, dyn = scenario_inputs(name)
@@ -79,11 +79,11 @@ def marshal_scenario(name, E=1, out_mask=None, solver=None):
     up_ptr, up_idx, _ = marshal.topology(p_struc, p)
     mp = marshal.member_params(p, p_LU, E)
     rp = marshal.reach_params(p_SC, p, E)
-    forcing, doy = marshal.forcing_arrays(met)
+    forcing, doy = marshal.forcing_arrays(met, snow=snow)
     scs = marshal.sc_list(p)
     opts = abi.make_opts(solver, dynamic_epc0=dyn['Dynamic_EPC0'] == 'y', dynamic_erod=dyn['Dynamic_erodibility'] == 'y',
                          run_mode_cal=p_SU.run_mode == 'cal', sc_qr0=scs.index(int(p['SC_Qr0'])),
-                         out_mask=marshal.MASK_ALL if out_mask is None else out_mask)
+                         out_mask=marshal.MASK_ALL if out_mask is None else out_mask, snow=snow)
     return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx, opts=opts,
                 scs=scs, met=met)
 

@@ -1,0 +1,110 @@
+"""the degree-day snow module (reference inputs.py:159-210) as a per-member prologue of the
+day loop (opts.snow = 1), so that ensembles can perturb f_DDSM / D_snow_0 without one forcing set per member.
+
+The recurrence is a handful of IEEE operations in a fixed order, so the in-kernel P is bit-identical to the host
+function's (which is bit-identical to the reference's own columns, tests/test_host.py): every comparison here is
+exact equality of whole output tables, against runs that were fed host-computed P series."""
+
+import numpy as np
+import pytest
+
+import helpers
+import simplyp_amd as sp
+from simplyp_amd import abi, marshal
+
+
+def snow_members(E, seed=11):
+    rng = np.random.default_rng(seed)
+    f_ddsm = rng.uniform(0.5, 6.0, E)
+    d0 = rng.uniform(0.0, 40.0, E)
+    f_ddsm[0], d0[0] = 2.74, 0.0                     # member 0 = the workbook
+    return f_ddsm, d0
+
+
+def per_member_forcing(met, f_ddsm, d0):
+    """[E][2][D]: P of every member from the host snow function, PET shared."""
+    rows = []
+    for f, d in zip(f_ddsm, d0):
+        m = sp.snow_hydrol_inputs(d, f, met[['T_air', 'PET', 'Precipitation']].copy())
+        rows.append(np.stack([m['P'].to_numpy(), m['PET'].to_numpy()]))
+    return np.ascontiguousarray(np.stack(rows))
+
+
+def setup(name, E, solver=None, out_mask=None):
+    m1 = helpers.marshal_scenario(name, E=E, solver=solver, out_mask=out_mask, snow=True)
+    m0 = helpers.marshal_scenario(name, E=E, solver=solver, out_mask=out_mask, snow=False)
+    f_ddsm, d0 = snow_members(E)
+    m1['member_params'][marshal.PM_NAMES.index('f_DDSM')] = f_ddsm
+    m1['member_params'][marshal.PM_NAMES.index('D_snow_0')] = d0
+    m0['forcing'] = per_member_forcing(m0['met'], f_ddsm, d0)
+    m0['fom'] = np.arange(E, dtype=np.int32)
+    return m1, m0
+
+
+def test_forcing_rows_and_parameters():
+    m1 = helpers.marshal_scenario('tarland_2004_static', E=2, snow=True)
+    met = m1['met']
+    assert m1['forcing'].shape == (1, 3, 366) and m1['opts'].snow == 1
+    assert np.array_equal(m1['forcing'][0, 0], met['Precipitation'].values) and np.array_equal(m1['forcing'][0, 2], met['T_air'].values)
+    assert marshal.PM_NAMES[-2:] == ['f_DDSM', 'D_snow_0'] and marshal.NP_M == 33
+    assert (m1['member_params'][-2] == 2.74).all() and (m1['member_params'][-1] == 0.0).all()
+
+
+@pytest.mark.parametrize('name', ['tarland_2004_dynamic', 'confluence3_nc_2004'])
+def test_oracle_snow_prologue_equals_host_snow_function(oracle_lib, name):
+    m1, m0 = setup(name, 5, solver=dict(integrator='rk4', substeps=16))
+    a, sa, _ = oracle_lib.run(m1['forcing'], m1['doy'], m1['member_params'], m1['reach_params'], m1['up_ptr'], m1['up_idx'], m1['opts'])
+    b, sb, _ = oracle_lib.run(m0['forcing'], m0['doy'], m0['member_params'], m0['reach_params'], m0['up_ptr'], m0['up_idx'], m0['opts'],
+                              forcing_of_member=m0['fom'])
+    assert np.array_equal(a, b, equal_nan=True) and sa.max() == 0
+    assert not np.array_equal(a[..., 0], a[..., 1])          # the snow parameters matter
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,solver', [('tarland_2004_dynamic', None), ('confluence3_nc_2004', dict(integrator='rk4', substeps=16)),
+                                         ('tarland_1981_2010_dynamic', dict(rtol=1e-6, atol=1e-8))])
+def test_kernel_snow_prologue_equals_host_snow_function(engine0, oracle_lib, name, solver):
+    E = 130
+    m1, m0 = setup(name, E, solver=solver, out_mask=marshal.MASK_REACH5 | marshal.mask_of_columns(['Qq', 'VsA']))
+    a, sa, _ = engine0.run(m1['forcing'], m1['doy'], m1['member_params'], m1['reach_params'], m1['up_ptr'], m1['up_idx'], m1['opts'])
+    b, sb, _ = engine0.run(m0['forcing'], m0['doy'], m0['member_params'], m0['reach_params'], m0['up_ptr'], m0['up_idx'], m0['opts'],
+                           forcing_of_member=m0['fom'])
+    import torch
+    assert bool(torch.equal(a, b)) and int(sa.max()) == 0 and bool(torch.isfinite(a).all())
+    if solver and solver.get('integrator') == 'rk4':            # and the oracle agrees (fixed step: rounding level)
+        ref, _, _ = oracle_lib.run(m1['forcing'], m1['doy'], m1['member_params'][:, :3], m1['reach_params'][:, :, :3],
+                                   m1['up_ptr'], m1['up_idx'], m1['opts'])
+        assert helpers.max_rel_err(a.cpu().numpy()[..., :3], ref, floor=1e-12) < 1e-10
+
+
+@pytest.mark.gpu
+def test_snow_state_crosses_time_chunks(engine0):
+    """Task-queue kernel: the snow depth is part of the state handed over between 256-day chunks."""
+    import torch
+    E = 200
+    m1, _ = setup('tarland_1981_2010_dynamic', E, solver=dict(rtol=1e-6, atol=1e-8, balance=0, time_chunk_days=-1), out_mask=marshal.MASK_REACH5)
+    D = 1500
+    m1['forcing'] = np.ascontiguousarray(m1['forcing'][:, :, :D]); m1['doy'] = np.ascontiguousarray(m1['doy'][:D])
+    ref, _, st0 = engine0.run(m1['forcing'], m1['doy'], m1['member_params'], m1['reach_params'], m1['up_ptr'], m1['up_idx'], m1['opts'])
+    m1['opts'].time_chunk_days, m1['opts'].balance, m1['opts'].balance_pilot_days = 256, 1, 100
+    got, _, st = engine0.run(m1['forcing'], m1['doy'], m1['member_params'], m1['reach_params'], m1['up_ptr'], m1['up_idx'], m1['opts'])
+    assert st0['queued'] == 0 and st['queued'] == 1 and st['balanced'] == 1
+    assert bool(torch.equal(got, ref))
+
+
+@pytest.mark.gpu
+def test_run_simply_p_ensemble_perturbs_snow_parameters(engine0):
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('tarland_2004_dynamic')
+    f = np.array([2.74, 1.0, 5.0])
+    args = lambda: (met.copy(), p_struc.copy(), p_SU.copy(), p_LU.copy(), p_SC.copy(), p.copy(), dyn.copy())
+    res = sp.run_simply_p_ensemble(*args(), overrides={'f_DDSM': f})
+    assert res['stats']['rhs_evals'] > 0
+    base = sp.run_simply_p_ensemble(*args(), n_members=1)                       # met_df['P'] as the reference feeds it
+    assert np.array_equal(res['data'][..., 0], base['data'][..., 0])
+    for k in (1, 2):                                                            # = a run on that member's own host-made P
+        mk = sp.snow_hydrol_inputs(p['D_snow_0'], f[k], met[['T_air', 'PET', 'Precipitation']].copy())
+        a = args()
+        one = sp.run_simply_p_ensemble(mk, *a[1:], n_members=1)
+        assert np.array_equal(res['data'][..., k], one['data'][..., 0])
+    with pytest.raises(ValueError, match='Precipitation'):
+        sp.run_simply_p_ensemble(met[['P', 'PET']].copy(), *args()[1:], overrides={'f_DDSM': f})
