@@ -371,6 +371,28 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         off_cptr.push_back(host.size()); host.insert(host.end(), L.chain_ptr.begin(), L.chain_ptr.end());
         off_creach.push_back(host.size()); host.insert(host.end(), L.chain_reach.begin(), L.chain_reach.end());
     }
+    // Pilot launches of the load balancer on a reach network: the routing schedule cut off PILOT_LEVELS reaches below the
+    // headwaters (chains keep their first elements; the slot assignments of the full schedule stay valid for a subset run
+    // in the same order).  Every reach of a member shares the member's parameters, so its cost rank among the members
+    // carries over to the reaches further down; a 256-reach chain is sampled by its first 8 reaches.
+    constexpr int PILOT_LEVELS = 8;
+    std::vector<int> level(S, 0);
+    for (int s = 0; s < S; ++s)
+        for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) level[s] = std::max(level[s], level[up_idx[k]] + 1);
+    std::vector<size_t> off_pilot_cptr, off_pilot_creach;
+    std::vector<unsigned> pilot_n_chains;
+    for (const Launch& L : sch.launches) {
+        std::vector<int> cptr(1, 0), creach;
+        for (size_t c = 0; c + 1 < L.chain_ptr.size(); ++c) {
+            for (int i = L.chain_ptr[c]; i < L.chain_ptr[c + 1] && level[L.chain_reach[i]] < PILOT_LEVELS; ++i)
+                creach.push_back(L.chain_reach[i]);
+            if ((int)creach.size() > cptr.back()) cptr.push_back((int)creach.size());
+        }
+        if (creach.empty()) continue;
+        pilot_n_chains.push_back((unsigned)cptr.size() - 1u);
+        off_pilot_cptr.push_back(host.size()); host.insert(host.end(), cptr.begin(), cptr.end());
+        off_pilot_creach.push_back(host.size()); host.insert(host.end(), creach.begin(), creach.end());
+    }
     rc = ensure(ctx, ctx->sched, host.size() * sizeof(int));
     if (rc != SIMPLYP_OK) return rc;
     // pageable source: the copy is staged before hipMemcpyAsync returns, `host` may go out of scope
@@ -406,23 +428,28 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     a.member_rhs = member_rhs_evals;
     const unsigned gx = (unsigned)((E + simplyp::WAVE - 1) / simplyp::WAVE);
     const bool snow = opts->snow != 0;
-    auto launch_all = [&](const simplyp::KernelArgs& base) -> int {
-        simplyp::KernelArgs k = base;
-        for (size_t l = 0; l < sch.launches.size(); ++l) {
-            k.chain_ptr = dsched + off_cptr[l];
-            k.chain_reach = dsched + off_creach[l];
-            const unsigned n_chains = (unsigned)sch.launches[l].chain_ptr.size() - 1u;
-            dim3 grid(gx, n_chains, 1), block(simplyp::WAVE, 1, 1);
+    // one launch of the chain kernel: k.chain_ptr / k.chain_reach describe n_chains mutually independent chains
+    auto launch_chains = [&](const simplyp::KernelArgs& k, unsigned n_chains) -> int {
+        dim3 grid(gx, n_chains, 1), block(simplyp::WAVE, 1, 1);
 #define SIMPLYP_LAUNCH_CHAIN(INTEG)                                                                                   \
     do {                                                                                                              \
         if (snow) hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, true>), grid, block, 0, ctx->stream, k);   \
         else hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, false>), grid, block, 0, ctx->stream, k);       \
     } while (0)
-            if (opts->integrator == SIMPLYP_INTEG_RK4) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_RK4);
-            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP);
-            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG_F32);
-            else SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG);
+        if (opts->integrator == SIMPLYP_INTEG_RK4) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_RK4);
+        else if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP);
+        else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG_F32);
+        else SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG);
 #undef SIMPLYP_LAUNCH_CHAIN
+        HIP_TRY(ctx, hipGetLastError());
+        return SIMPLYP_OK;
+    };
+    auto launch_all = [&](const simplyp::KernelArgs& base) -> int {
+        simplyp::KernelArgs k = base;
+        for (size_t l = 0; l < sch.launches.size(); ++l) {
+            k.chain_ptr = dsched + off_cptr[l];
+            k.chain_reach = dsched + off_creach[l];
+            if (int rc_l = launch_chains(k, (unsigned)sch.launches[l].chain_ptr.size() - 1u)) return rc_l;
             HIP_TRY(ctx, hipGetLastError());
         }
         return SIMPLYP_OK;
@@ -435,10 +462,19 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     // A short pilot run measures each member's cost; members are then handed to lane slots in order of
     // decreasing cost, so (a) the lanes of a wave need similar step counts and (b) the dispatcher starts
     // the long waves first and back-fills with the short ones (longest-processing-time-first).
+    int chunk_days = opts->time_chunk_days > 0 ? opts->time_chunk_days : 256;
+    chunk_days = ((chunk_days + simplyp::TILE_D - 1) / simplyp::TILE_D) * simplyp::TILE_D;
+    bool want_queue = opts->integrator != SIMPLYP_INTEG_RK4 && D > chunk_days &&
+        (opts->time_chunk_days > 0 ||
+         (opts->time_chunk_days == 0 && ((S == 1 && (int)gx > ctx->n_simd_slots) || (S > 1 && (int)gx < ctx->n_simd_slots))));
     int pilot_days = opts->balance_pilot_days > 0 ? opts->balance_pilot_days : 160;
     if (pilot_days > D) pilot_days = D;
+    // auto: a single-reach ensemble that needs more waves than the chip holds at once; a reach network that will run through
+    // the task queue with at least four member groups (there every SIMD works through many tasks, so homogeneous groups pay;
+    // with one wave per SIMD sorting only makes the slowest wave slower)
     const bool want_balance = opts->integrator != SIMPLYP_INTEG_RK4 && pilot_days * 4 <= D &&
-        (opts->balance == 1 || (opts->balance == 2 && (int)gx > ctx->n_simd_slots));
+        (opts->balance == 1 ||
+         (opts->balance == 2 && ((int)gx > ctx->n_simd_slots || (S > 1 && want_queue && gx >= 4u))));
     ctx->balanced = 0;
     if (want_balance) {
         rc = ensure(ctx, ctx->balance, (size_t)E * (sizeof(uint32_t) + sizeof(int32_t)));
@@ -451,7 +487,15 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         p.route_days = pilot_days;
         p.out_mask = 0u;                  // nothing is written
         p.member_rhs = d_cost;
-        rc = launch_all(p);
+        if (getenv("SIMPLYP_PILOT_ALL_REACHES")) {               // diagnostics: times the full-network pilot
+            rc = launch_all(p);
+        } else {
+            for (size_t l = 0; l < pilot_n_chains.size() && rc == SIMPLYP_OK; ++l) {
+                p.chain_ptr = dsched + off_pilot_cptr[l];
+                p.chain_reach = dsched + off_pilot_creach[l];
+                rc = launch_chains(p, pilot_n_chains[l]);
+            }
+        }
         if (rc != SIMPLYP_OK) return rc;
         std::vector<uint32_t> cost((size_t)E);
         HIP_TRY(ctx, hipMemcpyAsync(cost.data(), d_cost, (size_t)E * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -501,19 +545,12 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     // ---- task-queue kernel: (reach, time chunk, member group) tasks pulled by one persistent wave per SIMD ----
     // auto: when the chain kernel would leave SIMDs idle -- a single-reach ensemble that needs more waves than the chip
     // holds at once, or a multi-reach network (a chain walked by one thread per member cannot use more than E lanes)
-    int chunk_days = opts->time_chunk_days > 0 ? opts->time_chunk_days : 256;
-    chunk_days = ((chunk_days + simplyp::TILE_D - 1) / simplyp::TILE_D) * simplyp::TILE_D;
-    bool want_queue = opts->integrator != SIMPLYP_INTEG_RK4 && D > chunk_days &&
-        (opts->time_chunk_days > 0 ||
-         (opts->time_chunk_days == 0 && ((S == 1 && (int)gx > ctx->n_simd_slots) || (S > 1 && (int)gx < ctx->n_simd_slots))));
     ctx->queued = 0;
     if (want_queue) {
         const int G = (int)gx, n_chunks = (D + chunk_days - 1) / chunk_days;
         // levels, ring depth, downstream CSR, routing buffers
-        std::vector<int> level(S, 0), n_down(S, 0);
+        std::vector<int> n_down(S, 0);
         int max_jump = 0;
-        for (int s = 0; s < S; ++s)
-            for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) level[s] = std::max(level[s], level[up_idx[k]] + 1);
         for (int s = 0; s < S; ++s)
             for (int k = up_ptr[s]; k < up_ptr[s + 1]; ++k) { max_jump = std::max(max_jump, level[s] - level[up_idx[k]]); ++n_down[up_idx[k]]; }
         const int ring_chunks = std::min(n_chunks, max_jump + 1);
