@@ -26,6 +26,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, /opt/skills/guides/MI355X_MICRO
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64
 BYTES_PER_CD_REACH5 = 56         # 5 outputs x 8 B written + 2 forcing values x 8 B read per catchment-day
 MEMBERS_PER_GPU = 100000
+# fp64 operations of one Cash-Karp attempt of one member on the augmented system (6 right-hand sides + stage sums + error
+# norm + update), counted in the gfx950 ISA of simplyp_queue_kernel<2,false>'s attempt loop: 347 FMAs (x2) + 223 mul +
+# 84 add + 21 max + 13 rcp in the loop body, 15 FMAs in the masked update (Roofline)
+FLOPS_PER_ATTEMPT = 2 * (347 + 15) + 223 + 84 + 21 + 13
 
 
 def main():
@@ -138,7 +142,11 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_CD_REACH5 * float(E) * D,
                          "note": "the path is fp64-VALU-bound, not HBM-bound: see fp64_valu"},
             "fp64_valu": {"rhs_evals_per_catchment_day": rhs_per_cd, "simt_efficiency": stats.get('simt_efficiency'),
-                          "peak_tflops": FP64_VALU_PEAK_TFLOPS},
+                          "flops_per_attempt": FLOPS_PER_ATTEMPT,
+                          "achieved_tflops": FLOPS_PER_ATTEMPT * (rhs / 6.0) / (k_ms * 1e-3) / 1e12,
+                          "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                          "frac": FLOPS_PER_ATTEMPT * (rhs / 6.0) / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                          "note": "useful lane-attempts only (lanes idling in a diverged wave are not counted); peak = all-FMA issue"},
             "members_flagged": n_bad,
             "parity": None if args.no_parity else parity_check(eng, prob['opts']),
         }
@@ -177,7 +185,7 @@ def cpu_baseline(prob, D):
     reference cannot travel to this box) timed on the host cores, on a bounded sample of the same workload."""
     from oracle import oracle
     cores = min(os.cpu_count() or 1, 16)
-    n = 16 * cores                                   # ~0.08 core-seconds per member-30-years -> ~20 core-seconds
+    n = 32 * cores                                   # ~0.06 core-seconds per member-30-years -> ~30 core-seconds
     mp = prob['member_params'][:, :n].copy()
     rp = prob['reach_params'][:, :, :n].copy()
     t0 = time.perf_counter()
