@@ -119,6 +119,23 @@ def test_ragged_ensemble_sizes(engine0, oracle_lib, E):
     assert helpers.max_rel_err(got, ref, floor=FLOOR) < 1e-10
 
 
+@pytest.mark.parametrize('D', [1, 2, 255, 256, 257])
+def test_run_lengths_around_the_forcing_tile(engine0, oracle_lib, D):
+    """Forcing is staged through LDS in tiles of 256 days: one day, one tile exactly, one day more; chain kernel and
+    (forced) task-queue kernel, against the oracle."""
+    m = helpers.marshal_scenario('confluence3_nc_2004', E=70, solver=dict(integrator='cashkarp_aug', rtol=1e-10, atol=1e-12))
+    m['forcing'] = np.ascontiguousarray(m['forcing'][:, :, :D]); m['doy'] = np.ascontiguousarray(m['doy'][:D])
+    m['member_params'][marshal.PM_NAMES.index('T_g')] *= np.linspace(0.7, 1.3, 70)
+    got, status, st = gpu_run(engine0, m)
+    sub = dict(m, member_params=m['member_params'][:, :3], reach_params=m['reach_params'][:, :, :3])
+    ref, _, _ = cpu_run(oracle_lib, sub)
+    assert got.shape[1] == D and status.max() == 0
+    assert helpers.max_rel_err(got[..., :3], ref, floor=FLOOR) < 1e-8
+    m['opts'].time_chunk_days = 256                      # queue kernel needs more than one chunk: falls back when D <= 256
+    got2, _, st2 = gpu_run(engine0, m)
+    assert st2['queued'] == (1 if D > 256 else 0) and np.array_equal(got2, got, equal_nan=True)
+
+
 def test_output_selection_is_a_slice_of_the_full_output(engine0):
     full = helpers.marshal_scenario('confluence3_nc_2004', E=5)
     got_full, _, _ = gpu_run(engine0, full)
