@@ -246,7 +246,7 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
  *     pb = Qr**b_Q        ->  dpb/dt = b_Q pb (dQr/dt) / Qr   (same for pk = Qr**k_M)
  * and Vr is not a free variable at all: (:127-131) and Vr0 (:457-459) give Vr == L Qr**(1-b_Q) / (a_Q 86400),
  * i.e. Qr/Vr = pb a_Q 86400 / L.  Carrying EA, ES, pb, pk as four extra Runge-Kutta states (re-evaluated
- * exactly from VsA, VsS, Qr at the start of every day, pb and pk also every 16 accepted steps within a day,
+ * exactly from VsA, VsS, Qr at the start of every day, pb and pk also after every 8th attempted step within a day,
  * so they cannot drift) leaves a right-hand side of
  * ~70 multiply-adds and one reciprocal.  The solution is the same function of time; the truncation error
  * is of the same order and is held by the same error controller; its norm runs over the 7 physical states
@@ -255,7 +255,7 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
  * the Monte-Carlo members).  State vector z: VsA VsS Vg Qr Msus TDPr PPr EA ES pb pk | Qr_av Msus_out TDP_out PP_out.
  */
 #define NZ 15
-#define AUG_RESYNC 16
+#define AUG_RESYNC 8
 #define AUG_NERR 7
 static void ode_aug(const double* z, const ode_params* p, double invKv, double* dz)
 {
@@ -303,7 +303,7 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
 {
     double k[6][NZ], zt[NZ], zn[NZ], z[NZ];
     double t = 0.0, h = *h_carry;
-    int attempts = 0, since_sync = 0;
+    int attempts = 0;
     const double Kv = p->L_reach / (p->a_Q * 8.64 * 10000), invKv = 1.0 / Kv;
     if (!(h > 0.0) || h > T) h = T;
     if (!state_finite(y)) { y[5] = y[7] = y[9] = y[11] = NAN; st->poisoned = 1; return; }
@@ -349,15 +349,14 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
             memcpy(z, zn, sizeof(zn));
             t = (hh == rem) ? T : t + hh;
             st->steps++;
-            /* pb, pk ride a neutrally stable manifold (nothing damps their drift from Qr**b, Qr**k), so on a
-             * storm day of 100+ steps the local errors would add up: re-evaluate them every AUG_RESYNC steps */
-            if (++since_sync >= AUG_RESYNC && t < T) {
-                z[9] = pow(z[3], p->b_Q); z[10] = pow(z[3], p->k_M);
-                since_sync = 0;
-            }
         } else {
             st->rejected++;
         }
+        /* pb, pk ride a neutrally stable manifold (nothing damps their drift from Qr**b, Qr**k) and are not in the error
+         * norm, so on a storm day of 100+ steps the local errors would add up: re-evaluate them after every AUG_RESYNC-th
+         * attempt of the day, accepted or not (a member's attempts are its own history; in the kernel the lanes of a
+         * wavefront attempt in lockstep, so this test is wave-uniform there) */
+        if (attempts % AUG_RESYNC == 0 && t < T) { z[9] = pow(z[3], p->b_Q); z[10] = pow(z[3], p->k_M); }
         double fac;
         if (bad) fac = 0.2;
         else if (err == 0.0) fac = 5.0;

@@ -54,7 +54,7 @@ GOF_STATS = ['N obs', 'NSE', 'log NSE', 'r2', 'Bias (%)', 'nRMSD (%)', 'sum_log_
 # Solver settings used when the caller does not choose: Cash-Karp 5(4) with per-thread step
 # control on the augmented (transcendental-free) form of the system, at the tolerance that meets
 # the <= 1e-6 parity bar against odeint(rtol=atol=1e-12) with a 10x margin.
-DEFAULT_SOLVER = dict(integrator='cashkarp_aug', substeps=8, rtol=1e-8, atol=1e-10, max_steps=4000, project_vr=1,
+DEFAULT_SOLVER = dict(integrator='cashkarp_aug', substeps=8, rtol=1e-8, atol=1e-12, max_steps=4000, project_vr=1,
                       balance=2, balance_pilot_days=0, out_slot_order=0, time_chunk_days=0)
 
 

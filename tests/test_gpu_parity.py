@@ -296,6 +296,17 @@ def test_full_size_monte_carlo_properties(engine0, oracle_lib):
     ref, _, _ = cpu_run(oracle_lib, sub, n_threads=8)
     got = out[..., torch.as_tensor(pick, device=out.device)].cpu().numpy()
     assert helpers.max_rel_err(got, ref, floor=FLOOR) < 1e-7
+    # the working tolerance holds across the parameter distribution, not only for the golden members: every 16th member
+    # (4096 of them), all 10 957 days, REACH-5 columns, against the same kernel at rtol 1e-11 -- which the golden
+    # scenarios pin to the reference's tight solution to 1e-9 (test_kernel_matches_oracle / test_oracle_series)
+    tight = dict(pr)
+    tight['member_params'] = pr['member_params'][:, ::16]; tight['reach_params'] = pr['reach_params'][:, :, ::16]
+    tight['opts'] = abi.make_opts(dict(rtol=1e-11, atol=1e-13), dynamic_epc0=True, out_mask=marshal.MASK_REACH5)
+    truth = eng.run(tight['forcing'], tight['doy'], tight['member_params'], tight['reach_params'], tight['up_ptr'], tight['up_idx'],
+                    tight['opts'])[0]
+    rel = ((out[..., ::16] - truth).abs() / truth.abs()).amax(dim=(0, 1, 2))
+    assert float(rel.max()) < 1e-6, (float(rel.max()), int((rel > 1e-6).sum()))
+    del truth, rel
     # permutation invariance + shard == unsharded, on a 4096-member slice
     sl = np.arange(4096) * 16
     perm = rng.permutation(len(sl))
