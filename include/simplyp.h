@@ -117,10 +117,12 @@ typedef struct {
     int32_t  project_vr;     /* 1: at each day end reset Vr to the invariant of the reference's own equations,
                                 L_reach*Qr^(1-b_Q)/(a_Q*86400) (drift control; 0 = integrate Vr literally) */
     int32_t  balance;        /* member load balancing: 0 off, 1 on, 2 auto (on when the ensemble needs more waves
-                                than the chip holds at once).  A pilot run over the first balance_pilot_days days
-                                measures each member's cost; lane slots then take members by decreasing cost.
+                                than the chip holds at once, or a reach network that runs through the task queue).  Short pilot
+                                runs measure each member's cost in 8 windows of the forcing; lane slots then take members in
+                                blocks of decreasing total cost, ordered inside a block by cost pattern.
                                 Results are unchanged bit for bit (members are independent).              */
-    int32_t  balance_pilot_days;   /* 0 = default (160) */
+    int32_t  balance_pilot_days;   /* total days of the pilot, split into 8 windows spread over the first ~1.6 years;
+                                      0 = default (64)                                                          */
     int32_t  out_slot_order; /* 0: `out` is written in member order (when members were reordered for balance this is
                                 a scatter of 8-byte words: correct, but HBM sees ~4x the output bytes as partial-sector
                                 writes).  1: `out` is written in lane-slot order, fully coalesced, and the caller gets

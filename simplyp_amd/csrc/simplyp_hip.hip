@@ -600,7 +600,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     bool want_queue = opts->integrator != SIMPLYP_INTEG_RK4 && D > chunk_days &&
         (opts->time_chunk_days > 0 ||
          (opts->time_chunk_days == 0 && ((S == 1 && (int)gx > ctx->n_simd_slots) || (S > 1 && (int)gx < ctx->n_simd_slots))));
-    int pilot_days = opts->balance_pilot_days > 0 ? opts->balance_pilot_days : 160;
+    int pilot_days = opts->balance_pilot_days > 0 ? opts->balance_pilot_days : 64;
     if (pilot_days > D) pilot_days = D;
     // auto: a single-reach ensemble that needs more waves than the chip holds at once; a reach network that will run through
     // the task queue with at least four member groups (there every SIMD works through many tasks, so homogeneous groups pay;
@@ -615,7 +615,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         // counter per member and window.
         constexpr int PILOT_WINDOWS = 8;
         const int win_days = std::max(1, pilot_days / PILOT_WINDOWS);
-        const int win_stride = std::max(win_days, std::min(4 * win_days, (D - win_days) / (PILOT_WINDOWS - 1)));
+        const int win_stride = std::max(win_days, std::min(80, (D - win_days) / (PILOT_WINDOWS - 1)));      // ~1.6 years covered
         rc = ensure(ctx, ctx->balance, (size_t)E * (PILOT_WINDOWS * sizeof(uint32_t) + sizeof(int32_t)));
         if (rc != SIMPLYP_OK) return rc;
         uint32_t* d_cost = (uint32_t*)ctx->balance.ptr;

@@ -9,7 +9,7 @@ E = 100000
 pr = synthetic.c3_problem(E, solver=dict(out_slot_order=1))
 dev = [eng.to_device(pr[k]) for k in ('forcing', 'doy', 'member_params', 'reach_params')]
 o = None
-for days in (48, 64, 96, 128, 160, 224, 320, 480):
+for days in (32, 48, 64, 96, 128, 160, 224):
     pr['opts'].balance_pilot_days = days
     for rep in range(2):
         o, st, stats = eng.run(dev[0], dev[1], dev[2], dev[3], pr['up_ptr'], pr['up_idx'], pr['opts'], out=o)
