@@ -21,39 +21,11 @@ def window_cost(start, length):
     return cost.cpu().numpy().astype(float)
 
 
-def features(kind):
-    if kind == 'contig8x20':
-        pref = np.stack([window_cost(0, 20 * (k + 1)) for k in range(8)])
-        return np.diff(np.concatenate([np.zeros((1, E)), pref]), axis=0)
-    if kind == 'spread8x20':
-        return np.stack([window_cost(80 * k, 20) for k in range(8)])
-    if kind == 'spread16x10':
-        return np.stack([window_cost(45 * k, 10) for k in range(16)])
-    if kind == 'spread8x20_4y':
-        return np.stack([window_cost(170 * k, 20) for k in range(8)])
-
-
 def pcs(feat):
     lf = np.log(feat + 1.0)
     z = (lf - lf.mean(1, keepdims=True)) / (lf.std(1, keepdims=True) + 1e-12)
     u, s, vt = np.linalg.svd(z, full_matrices=False)
     return u.T @ z
-
-
-def two_level(total, key2, nb1):
-    b1 = np.floor(np.argsort(np.argsort(-total)) / (E / nb1)).astype(int)
-    return np.lexsort((key2 * np.where(b1 % 2 == 0, 1.0, -1.0), b1)), b1
-
-
-def three_level(total, pc, nb1, nb2):
-    order2, b1 = two_level(total, pc[1], nb1)
-    b2 = np.zeros(E, dtype=int)
-    for b in range(nb1):
-        idx = np.flatnonzero(b1 == b)
-        r = np.argsort(np.argsort(pc[1][idx]))
-        b2[idx] = np.floor(r / (len(idx) / nb2)).astype(int)
-    snake = np.where((b1 * nb2 + b2) % 2 == 0, 1.0, -1.0)
-    return np.lexsort((pc[2] * snake, b2, b1))
 
 
 o = None
@@ -65,12 +37,35 @@ def run(name, order):
     print('%-40s kernel %.1f ms simt %.4f' % (name, stats['kernel_ms'], stats['simt_efficiency']), flush=True)
 
 
-for kind in ('contig8x20', 'spread8x20', 'spread16x10', 'spread8x20_4y'):
-    feat = features(kind)
-    total = feat.sum(0)
-    pc = pcs(feat)
-    run(kind + ' total', np.argsort(-total, kind='stable'))
-    for nb1 in (12, 48, 192):
-        run(kind + ' total%d/pc2' % nb1, two_level(total, pc[1], nb1)[0])
-    run(kind + ' total24/pc2x6/pc3', three_level(total, pc, 24, 6))
-    run(kind + ' total12/pc2x12/pc3', three_level(total, pc, 12, 12))
+def hier(total, pc, nbs, final_key):
+    """nested blocks: nbs[0] by total, nbs[1] by pc[1], nbs[2] by pc[2], ...; leaves sorted by final_key"""
+    order = np.argsort(-total, kind='stable')
+    groups = [order]
+    for lvl, nb in enumerate(nbs):
+        new = []
+        for gi, g in enumerate(groups):
+            if lvl > 0:
+                k = pc[lvl][g] * (1.0 if gi % 2 == 0 else -1.0)
+                g = g[np.argsort(k, kind='stable')]
+            new += [g[len(g) * i // nb: len(g) * (i + 1) // nb] for i in range(nb)]
+        groups = new
+    out = []
+    for gi, g in enumerate(groups):
+        k = final_key[g] * (1.0 if gi % 2 == 0 else -1.0)
+        out.append(g[np.argsort(k, kind='stable')])
+    return np.concatenate(out)
+
+
+feat = np.stack([window_cost(80 * k, 8) for k in range(8)])
+total = feat.sum(0)
+pc = pcs(feat)
+run('total', np.argsort(-total, kind='stable'))
+run('24/6/pc3 (library)', hier(total, pc, [24, 6], pc[2]))
+run('24/4/4/pc4', hier(total, pc, [24, 4, 4], pc[3]))
+run('48/4/pc3', hier(total, pc, [48, 4], pc[2]))
+run('12/8/pc3', hier(total, pc, [12, 8], pc[2]))
+run('24/6/3/total', hier(total, pc, [24, 6, 3], -total))
+run('24/6/total', hier(total, pc, [24, 6], -total))
+run('96/pc2', hier(total, pc, [96], pc[1]))
+run('24/12/pc3', hier(total, pc, [24, 12], pc[2]))
+run('8/8/8/pc4', hier(total, pc, [8, 8, 8], pc[3]))
