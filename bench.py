@@ -136,7 +136,7 @@ def main():
                                       "per-member summaries" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "simplyp_%s_kernel<%d>" % ("queue" if stats.get('queued') else "chain", prob['opts'].integrator),
+                         "kernel": "simplyp_%s_kernel<%d, false>" % ("queue" if stats.get('queued') else "chain", prob['opts'].integrator),
                          "kernel_ms": k_ms,
                          "pilot_ms": stats.get('pilot_ms', 0.0),
                          "algorithmic_bytes_per_launch": BYTES_PER_CD_REACH5 * float(E) * D,
