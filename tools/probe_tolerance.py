@@ -20,9 +20,9 @@ def run(solver):
 truth, st, _ = run(dict(rtol=1e-11, atol=1e-13))
 print('truth flagged', int((st != 0).sum()), flush=True)
 print('lib', engine.LIB_PATH)
-for rtol, atol in ((1e-8, 1e-12), (2e-8, 1e-12), (3e-8, 1e-12)):
+for rtol, atol in (((1e-8, 1e-12),) if E > 20000 else ((1e-8, 1e-12), (2e-8, 1e-12), (3e-8, 1e-12))):
     out, st, stats = run(dict(rtol=rtol, atol=atol))
-    rel = ((out - truth).abs() / truth.abs().clamp_min(1e-300))
+    rel = (out - truth).abs_().div_(truth.abs().clamp_min(1e-300))
     per_member = rel.amax(dim=(0, 1, 2))                      # [E]
     per_col = rel.amax(dim=(1, 2, 3))
     q = torch.quantile(per_member.float(), torch.tensor([0.5, 0.99, 0.999], device=per_member.device))
