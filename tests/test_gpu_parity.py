@@ -331,6 +331,22 @@ def test_full_size_monte_carlo_properties(engine0, oracle_lib):
     assert helpers.max_rel_err(o2[0, :, 0, :], inv) < 1e-12
 
 
+def test_load_balancer_groups_members_with_similar_step_patterns(engine0):
+    """What the pilot + ordering is for: lanes of a wavefront that need similar step counts day by day.  On the bench's
+    Monte-Carlo distribution the fraction of issued lane-attempts that were needed (stats.simt_efficiency) rises from
+    ~0.63 (members as drawn) to ~0.82; asserted with margin, on a 3-year slice."""
+    pr = synthetic.c3_problem(70000, end_dt='1983-12-31', solver=dict(out_slot_order=1))
+    eff = {}
+    for balance in (0, 1):
+        pr['opts'].balance = balance
+        out, status, st = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], pr['opts'])
+        assert st['balanced'] == balance and int(status.max()) == 0
+        eff[balance] = st['simt_efficiency']
+        mos = st['member_of_slot'].cpu().numpy()
+        assert sorted(mos.tolist()) == list(range(70000))
+    assert eff[0] < 0.70 and eff[1] > 0.78 and eff[1] - eff[0] > 0.12, eff
+
+
 @pytest.mark.parametrize('name', ['tarland_2004_dynamic', 'chain4_val_2004', 'confluence3_nc_2004'])
 def test_load_balanced_run_is_bitwise_identical(engine0, name):
     """opts.balance = 1 (pilot run + cost-sorted lane slots, routing series kept in slot order): outputs,
