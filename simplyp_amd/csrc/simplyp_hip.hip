@@ -481,12 +481,8 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    // ---- device scratch: routing series, schedule, counters ----
-    const size_t slot_bytes = (size_t)4 * D * E * sizeof(double);
-    if (sch.n_slots > 0) {
-        rc = ensure(ctx, ctx->route, slot_bytes * sch.n_slots);
-        if (rc != SIMPLYP_OK) return rc;
-    }
+    // ---- device scratch: schedule, counters (the routing series are sized where their length is known: pilot windows,
+    // ring buffers of the task queue, or whole-run series of the chain kernel) ----
     rc = ensure(ctx, ctx->counters, 4 * sizeof(unsigned long long));
     if (rc != SIMPLYP_OK) return rc;
 
@@ -624,6 +620,11 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         simplyp::KernelArgs p = a;
         p.D = win_days;                   // forcing rows keep their stride of D days
         p.route_days = win_days;
+        if (sch.n_slots > 0) {
+            rc = ensure(ctx, ctx->route, (size_t)sch.n_slots * 4 * win_days * E * sizeof(double));
+            if (rc != SIMPLYP_OK) return rc;
+            p.route = (double*)ctx->route.ptr;
+        }
         p.out_mask = 0u;                  // nothing is written
         for (int w = 0; w < PILOT_WINDOWS && rc == SIMPLYP_OK; ++w) {
             const size_t off = (size_t)w * win_stride;
@@ -766,6 +767,11 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         }
     }
     if (!want_queue) {
+        if (sch.n_slots > 0) {           // whole-run daily series of every reach that is read downstream
+            rc = ensure(ctx, ctx->route, (size_t)sch.n_slots * 4 * D * E * sizeof(double));
+            if (rc != SIMPLYP_OK) return rc;
+        }
+        a.route = (double*)ctx->route.ptr;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
         rc = launch_all(a);
         if (rc != SIMPLYP_OK) return rc;
