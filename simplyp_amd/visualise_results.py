@@ -98,4 +98,16 @@ def _no_plots(name):
 plot_snow = _no_plots('plot_snow')
 plot_terrestrial = _no_plots('plot_terrestrial')
 plot_in_stream = _no_plots('plot_in_stream')
-plot_instream_summed = _no_plots('plot_instream_summed')
+
+
+def plot_instream_summed(p_SU, df_summed, fig_display_type=None):
+    """The reference function draws the summed series and -- its only data side effect -- writes
+    ``Instream_results_receiving_waterbody.csv`` when ``p_SU.save_output_csvs == 'y'`` (visualise_results.py:382-384; one of
+    the three on-disk result formats).  This stand-in writes that file (same name, same
+    ``to_csv`` call, same printed line); the figure itself is outside the scope of simplyp_amd, so asking for it
+    (``p_SU.plot_R == 'y'``) raises ``NotImplementedError`` after the file is written."""
+    if p_SU.save_output_csvs == 'y':
+        df_summed.to_csv(os.path.join(p_SU.output_fpath, "Instream_results_receiving_waterbody.csv"))
+        print('Results saved to csv')
+    if p_SU.plot_R == 'y':
+        _no_plots('plot_instream_summed')()

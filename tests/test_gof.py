@@ -115,6 +115,22 @@ def test_observation_array_layout():
 
 
 def test_plotting_names_exist_and_refuse():
-    for name in ('plot_snow', 'plot_terrestrial', 'plot_in_stream', 'plot_instream_summed'):
+    for name in ('plot_snow', 'plot_terrestrial', 'plot_in_stream'):
         with pytest.raises(NotImplementedError, match='outside the scope'):
             getattr(sp, name)()
+
+
+def test_waterbody_csv_is_written_by_plot_instream_summed(tmp_path, capsys):
+    """visualise_results.py:382-384: the third on-disk result format comes out of the plotting function."""
+    idx = pd.date_range('2004-01-01', periods=3)
+    df = pd.DataFrame({'Q_cumecs': [1.0, 2.0, 3.0], 'TP_mgl': [0.1, 0.2, 0.3]}, index=idx)
+    p_SU = pd.Series(dict(save_output_csvs='y', output_fpath=str(tmp_path), plot_R='n'), dtype=object)
+    sp.plot_instream_summed(p_SU, df, 'paper')
+    assert 'Results saved to csv' in capsys.readouterr().out
+    back = pd.read_csv(tmp_path / 'Instream_results_receiving_waterbody.csv', index_col=0, parse_dates=True)
+    assert list(back.columns) == ['Q_cumecs', 'TP_mgl'] and np.allclose(back.to_numpy(), df.to_numpy())
+    p_SU['plot_R'] = 'y'
+    with pytest.raises(NotImplementedError, match='outside the scope'):
+        sp.plot_instream_summed(p_SU, df, 'paper')
+    p_SU['save_output_csvs'], p_SU['plot_R'] = 'n', 'n'
+    assert sp.plot_instream_summed(p_SU, df, 'paper') is None
