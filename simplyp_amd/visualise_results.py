@@ -4,7 +4,8 @@ ensembles use instead (``gof_ensemble`` -> ``simplyp_gof`` of the C ABI, SURVEY.
 
 The reference's plotting functions (``plot_snow``, ``plot_terrestrial``, ``plot_in_stream``,
 ``plot_instream_summed``; matplotlib/seaborn figures) are outside the scope of this engine: the names exist and raise
-``NotImplementedError`` so that a notebook fails at the plotting cell with a clear message, not at import.
+``NotImplementedError`` so that a notebook fails at the plotting cell with a clear message, not at import
+(``plot_instream_summed`` first writes the receiving-waterbody CSV, the reference function's data side effect).
 """
 
 import os
