@@ -550,6 +550,7 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     a.rtol = opts->rtol; a.atol = opts->atol; a.step_len = opts->step_len;
 
     a.D_stride = D;
+    a.win_stride = 0; a.win_route_stride = 0;
     a.route_days = D;
     a.perm = nullptr;
     a.out_by_slot = 0;
@@ -558,8 +559,8 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     const unsigned gx = (unsigned)((E + simplyp::WAVE - 1) / simplyp::WAVE);
     const bool snow = opts->snow != 0;
     // one launch of the chain kernel: k.chain_ptr / k.chain_reach describe n_chains mutually independent chains
-    auto launch_chains = [&](const simplyp::KernelArgs& k, unsigned n_chains) -> int {
-        dim3 grid(gx, n_chains, 1), block(simplyp::WAVE, 1, 1);
+    auto launch_chains = [&](const simplyp::KernelArgs& k, unsigned n_chains, unsigned n_windows = 1u) -> int {
+        dim3 grid(gx, n_chains, n_windows), block(simplyp::WAVE, 1, 1);
 #define SIMPLYP_LAUNCH_CHAIN(INTEG)                                                                                   \
     do {                                                                                                              \
         if (snow) hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, true>), grid, block, 0, ctx->stream, k);   \
@@ -620,25 +621,31 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
         simplyp::KernelArgs p = a;
         p.D = win_days;                   // forcing rows keep their stride of D days
         p.route_days = win_days;
+        const size_t win_route = (size_t)sch.n_slots * 4 * win_days * E;      // doubles of routing scratch per window
         if (sch.n_slots > 0) {
-            rc = ensure(ctx, ctx->route, (size_t)sch.n_slots * 4 * win_days * E * sizeof(double));
+            rc = ensure(ctx, ctx->route, (size_t)PILOT_WINDOWS * win_route * sizeof(double));
             if (rc != SIMPLYP_OK) return rc;
             p.route = (double*)ctx->route.ptr;
         }
-        p.out_mask = 0u;                  // nothing is written
-        for (int w = 0; w < PILOT_WINDOWS && rc == SIMPLYP_OK; ++w) {
-            const size_t off = (size_t)w * win_stride;
-            p.forcing = a.forcing + off;
-            p.doy = a.doy ? a.doy + off : nullptr;
-            p.member_rhs = d_cost + (size_t)w * E;
-            if (getenv("SIMPLYP_PILOT_ALL_REACHES")) {           // diagnostics: times the full-network pilot
-                rc = launch_all(p);
-            } else {
-                for (size_t l = 0; l < pilot_n_chains.size() && rc == SIMPLYP_OK; ++l) {
-                    p.chain_ptr = dsched + off_pilot_cptr[l];
-                    p.chain_reach = dsched + off_pilot_creach[l];
-                    rc = launch_chains(p, pilot_n_chains[l]);
-                }
+        // all windows in one launch per schedule level (blockIdx.z = window): 8 x 1563 waves fill the chip's rounds, where
+        // 8 launches of 1563 waves would each leave a half-empty second round
+        p.win_stride = win_stride;
+        p.win_route_stride = (long long)win_route;
+        p.member_rhs = d_cost;
+        if (getenv("SIMPLYP_PILOT_ALL_REACHES")) {               // diagnostics: times the full-network pilot
+            for (int w = 0; w < PILOT_WINDOWS && rc == SIMPLYP_OK; ++w) {
+                simplyp::KernelArgs pw = p;
+                pw.win_stride = 0;
+                pw.forcing = a.forcing + (size_t)w * win_stride;
+                pw.doy = a.doy ? a.doy + (size_t)w * win_stride : nullptr;
+                pw.member_rhs = d_cost + (size_t)w * E;
+                rc = launch_all(pw);
+            }
+        } else {
+            for (size_t l = 0; l < pilot_n_chains.size() && rc == SIMPLYP_OK; ++l) {
+                p.chain_ptr = dsched + off_pilot_cptr[l];
+                p.chain_reach = dsched + off_pilot_creach[l];
+                rc = launch_chains(p, pilot_n_chains[l], (unsigned)PILOT_WINDOWS);
             }
         }
         if (rc != SIMPLYP_OK) return rc;

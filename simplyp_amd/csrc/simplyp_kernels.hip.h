@@ -56,6 +56,9 @@ struct KernelArgs {
     int n_out_reaches;
     unsigned out_mask;
     int integrator, substeps, max_steps;
+    int win_stride;                 // pilot of the load balancer: blockIdx.z runs the window of the forcing that starts
+                                    // win_stride * blockIdx.z days in, with its own cost counters and routing scratch (0 = off)
+    long long win_route_stride;     // doubles of routing scratch per window
     int dynamic_epc0, dynamic_erod, run_mode_cal, sc_qr0, project_vr;
     double rtol, atol, step_len;
 };
@@ -951,6 +954,16 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs
     __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
     const int c0 = a.chain_ptr[blockIdx.y], c1 = a.chain_ptr[blockIdx.y + 1];
+    if (a.win_stride > 0) {      // pilot windows: the same short run over different stretches of the forcing
+        KernelArgs w = a;
+        const size_t off = (size_t)blockIdx.z * a.win_stride;
+        w.forcing = a.forcing + off;
+        w.doy = a.doy ? a.doy + off : nullptr;
+        w.member_rhs = a.member_rhs + (size_t)blockIdx.z * a.E;
+        w.route = a.route ? a.route + (size_t)blockIdx.z * a.win_route_stride : nullptr;
+        run_slot<INTEG, SNOW>(w, s_P, s_E, s_T, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+        return;
+    }
     run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
 }
 
