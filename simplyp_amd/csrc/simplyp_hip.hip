@@ -193,11 +193,15 @@ template <class F>
 void parallel_for(int n, F fn)
 {
     const int n_thr = std::max(1, std::min({n, 8, (int)std::thread::hardware_concurrency()}));
-    if (n_thr == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    std::vector<std::thread> pool;
     std::atomic<int> next(0);
-    for (int t = 0; t < n_thr; ++t)
-        pool.emplace_back([&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
+    auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work);
+    } catch (...) {
+        // no more threads to be had: the calling thread does whatever the started ones do not
+    }
+    work();
     for (std::thread& t : pool) t.join();
 }
 
@@ -431,8 +435,8 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
     return (int64_t)popcount32(opts->out_mask & SIMPLYP_MASK_ALL) * rows * nor * dims->E * (int64_t)sizeof(double);
 }
 
-int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_t* n_launches, int32_t* n_slots,
-                 int32_t* launch_of_reach, int32_t* chain_of_reach, int32_t* pos_in_chain, int32_t* route_slot)
+static int plan_impl(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_t* n_launches, int32_t* n_slots,
+                     int32_t* launch_of_reach, int32_t* chain_of_reach, int32_t* pos_in_chain, int32_t* route_slot)
 {
     if (S <= 0 || !up_ptr || (up_ptr[S] > 0 && !up_idx)) return fail(nullptr, SIMPLYP_ERR_ARG, "bad plan arguments");
     simplyp_ctx tmp;
@@ -455,13 +459,29 @@ int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_
     return SIMPLYP_OK;
 }
 
-int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
-                      const double* forcing, const int32_t* doy, const int32_t* period_of_day,
-                      const int32_t* forcing_of_member,
-                      const double* member_params, const double* reach_params,
-                      const int32_t* up_ptr, const int32_t* up_idx,
-                      const int32_t* out_reaches, int32_t n_out_reaches,
-                      double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals)
+// Host-side C++ (std::vector, std::thread) must not throw across the C boundary.
+#define SIMPLYP_GUARD(ctx, call)                                                                    \
+    try {                                                                                           \
+        return call;                                                                                \
+    } catch (const std::bad_alloc&) {                                                               \
+        return fail(ctx, SIMPLYP_ERR_NOMEM, "host memory allocation failed");                       \
+    } catch (const std::exception& e) {                                                             \
+        return fail(ctx, SIMPLYP_ERR_DEVICE, "unexpected host error: %s", e.what());                \
+    }
+
+int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_t* n_launches, int32_t* n_slots,
+                 int32_t* launch_of_reach, int32_t* chain_of_reach, int32_t* pos_in_chain, int32_t* route_slot)
+{
+    SIMPLYP_GUARD(nullptr, plan_impl(S, up_ptr, up_idx, n_launches, n_slots, launch_of_reach, chain_of_reach, pos_in_chain, route_slot))
+}
+
+static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
+                          const double* forcing, const int32_t* doy, const int32_t* period_of_day,
+                          const int32_t* forcing_of_member,
+                          const double* member_params, const double* reach_params,
+                          const int32_t* up_ptr, const int32_t* up_idx,
+                          const int32_t* out_reaches, int32_t n_out_reaches,
+                          double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals)
 {
     int rc = check_args(ctx, dims, opts, forcing, member_params, reach_params, up_ptr, out, member_status,
                         out_reaches, n_out_reaches);
@@ -789,6 +809,19 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
     return SIMPLYP_OK;
 }
 
+int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
+                      const double* forcing, const int32_t* doy, const int32_t* period_of_day,
+                      const int32_t* forcing_of_member,
+                      const double* member_params, const double* reach_params,
+                      const int32_t* up_ptr, const int32_t* up_idx,
+                      const int32_t* out_reaches, int32_t n_out_reaches,
+                      double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals)
+{
+    SIMPLYP_GUARD(ctx, run_async_impl(ctx, dims, opts, forcing, doy, period_of_day, forcing_of_member, member_params, reach_params,
+                                      up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status, member_of_slot,
+                                      member_rhs_evals))
+}
+
 int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
 {
     if (!ctx) return SIMPLYP_ERR_ARG;
@@ -839,11 +872,11 @@ int simplyp_run(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* 
     return simplyp_sync(ctx, stats);
 }
 
-int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
-                const int32_t* out_reaches, int32_t n_out_reaches,
-                const double* out, const int32_t* member_of_slot,
-                const double* f_tdp, const double* reach_params,
-                const double* obs, double* gof, simplyp_gof_info* info)
+static int gof_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                    const int32_t* out_reaches, int32_t n_out_reaches,
+                    const double* out, const int32_t* member_of_slot,
+                    const double* f_tdp, const double* reach_params,
+                    const double* obs, double* gof, simplyp_gof_info* info)
 {
     if (!ctx) return SIMPLYP_ERR_ARG;
     if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is pending on this context; call simplyp_sync first");
@@ -985,6 +1018,15 @@ int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
         info->n_chunks_chem = n_chunks_c;
     }
     return SIMPLYP_OK;
+}
+
+int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                const int32_t* out_reaches, int32_t n_out_reaches,
+                const double* out, const int32_t* member_of_slot,
+                const double* f_tdp, const double* reach_params,
+                const double* obs, double* gof, simplyp_gof_info* info)
+{
+    SIMPLYP_GUARD(ctx, gof_impl(ctx, dims, out_mask, out_reaches, n_out_reaches, out, member_of_slot, f_tdp, reach_params, obs, gof, info))
 }
 
 void* simplyp_host_alloc(int64_t bytes)
