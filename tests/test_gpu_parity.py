@@ -202,7 +202,7 @@ def test_argument_errors_come_back_as_exceptions(engine0):
 # ---------------------------------------------------------------------------------------------------
 # the drop-in API
 
-@pytest.mark.parametrize('name', SCENARIOS)
+@pytest.mark.parametrize('name', SCENARIOS + ['tarland_1981_2010_dynamic'])
 def test_run_simply_p_drop_in(engine0, name, capsys):
     """run_simply_p on the reference's inputs: same tables (names, order, index), same in-place edits of
     p_LU / p_SC, same Kf, same printed lines as the reference produced for the golden run."""
