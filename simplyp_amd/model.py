@@ -230,7 +230,7 @@ def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len
 
 def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
                           outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True,
-                          reduce=None, obs_dict=None, keep_daily=True, snow_in_kernel=None):
+                          reduce=None, obs_dict=None, keep_daily=True, snow_in_kernel=None, forcing_of_member=None):
     """Run an ensemble of parameter sets through the engine in one call.
 
     ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
@@ -240,6 +240,8 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     sub-catchment ids to return (default all).  ``reduce``: None for daily rows, ``'annual'`` for one row
     per calendar year holding the sum of that year's daily values (e.g. annual fluxes), or an int array
     [D] of period indices; the periods are returned under ``'periods'``.
+    ``met_df`` may also be a list of met dataframes over the same dates (forcing scenarios: climate members, bias-corrected
+    series ...) with ``forcing_of_member`` [E] giving each member's scenario; all sets sit in HBM once and members read theirs.
     ``snow_in_kernel``: run the degree-day snow module (reference ``snow_hydrol_inputs``, inputs.py:159-210) per member
     inside the kernel from ``met_df['Precipitation']`` / ``['T_air']`` instead of taking ``met_df['P']``; default: on when
     ``overrides`` perturbs ``f_DDSM`` or ``D_snow_0`` (with the workbook values the result is bit-identical either way).
@@ -273,9 +275,23 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     rp = marshal.reach_params(p_SC, p, E, r_over)
     if snow_in_kernel is None:
         snow_in_kernel = 'f_DDSM' in m_over or 'D_snow_0' in m_over
-    if snow_in_kernel and not {'Precipitation', 'T_air'} <= set(met_df.columns):
-        raise ValueError("the in-kernel snow module needs met_df columns 'Precipitation' and 'T_air'")
-    forcing, doy = marshal.forcing_arrays(met_df, snow=snow_in_kernel)
+    met_sets = list(met_df) if isinstance(met_df, (list, tuple)) else [met_df]
+    met_df = met_sets[0]
+    for m in met_sets:
+        if snow_in_kernel and not {'Precipitation', 'T_air'} <= set(m.columns):
+            raise ValueError("the in-kernel snow module needs met_df columns 'Precipitation' and 'T_air'")
+        if not m.index.equals(met_df.index):
+            raise ValueError("all forcing sets must cover the same dates")
+    if len(met_sets) > 1:
+        if forcing_of_member is None:
+            raise ValueError("several forcing sets need forcing_of_member (one set index per member)")
+        forcing_of_member = np.ascontiguousarray(forcing_of_member, dtype=np.int32)
+        if forcing_of_member.shape != (E,) or forcing_of_member.min() < 0 or forcing_of_member.max() >= len(met_sets):
+            raise ValueError("forcing_of_member needs one index in [0, %d) per member" % len(met_sets))
+    elif forcing_of_member is not None:
+        raise ValueError("forcing_of_member given but met_df is a single forcing set")
+    parts = [marshal.forcing_arrays(m, snow=snow_in_kernel) for m in met_sets]
+    forcing, doy = np.ascontiguousarray(np.concatenate([f for f, _ in parts], axis=0)), parts[0][1]
     cols = list(outputs) if outputs is not None else list(marshal.REACH5_COLUMNS)
     if obs_dict is not None:
         if reduce is not None:
@@ -302,7 +318,7 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     eng = engine.get_engine(device)
     rp_d = eng.to_device(rp)
     out_d, status_d, stats = eng.run(forcing, doy, mp, rp_d, up_ptr, up_idx, opts, out_reaches=oreach,
-                                     period_of_day=period_of_day)
+                                     period_of_day=period_of_day, forcing_of_member=forcing_of_member)
     marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)
     reaches = scs if out_reaches is None else list(out_reaches)
     res = dict(columns=marshal.columns_of_mask(mask), reaches=reaches, periods=periods, stats=stats,

@@ -253,6 +253,25 @@ def test_run_simply_p_validation_errors_before_any_launch(engine0):
         sp.run_simply_p(met, p_struc, p_SU, p_LU, p_SC, p, dyn)
 
 
+def test_run_simply_p_ensemble_with_forcing_scenarios(engine0):
+    """A list of met dataframes + forcing_of_member: every member equals a single-scenario run of its own set."""
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('tarland_2004_dynamic')
+    wet = met.copy(); wet['P'] = wet['P'] * 1.2
+    warm = met.copy(); warm['PET'] = warm['PET'] * 1.3
+    args = lambda m: (m, p_struc.copy(), p_SU.copy(), p_LU.copy(), p_SC.copy(), p.copy(), dyn.copy())
+    fom = np.array([0, 1, 2, 1, 0])
+    fc = np.array([290.0, 270.0, 310.0, 290.0, 280.0])
+    res = sp.run_simply_p_ensemble(*args([met, wet, warm]), overrides={'fc': fc}, forcing_of_member=fom)
+    for k, m in enumerate((met, wet, warm)):
+        pick = np.flatnonzero(fom == k)
+        one = sp.run_simply_p_ensemble(*args(m.copy()), overrides={'fc': fc[pick]})
+        assert np.array_equal(res['data'][..., pick], one['data'])
+    with pytest.raises(ValueError, match='forcing_of_member'):
+        sp.run_simply_p_ensemble(*args([met, wet]), overrides={'fc': fc})
+    with pytest.raises(ValueError, match='same dates'):
+        sp.run_simply_p_ensemble(*args([met, wet.iloc[:-1]]), overrides={'fc': fc}, forcing_of_member=fom % 2)
+
+
 def test_run_simply_p_ensemble_overrides(engine0, oracle_lib):
     met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('chain4_val_2004')
     E = 10
