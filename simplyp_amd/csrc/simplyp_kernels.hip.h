@@ -411,18 +411,31 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     typedef typename SYS::real R;       // working precision of the stages (the daily integrals yq stay fp64)
     constexpr int NS = SYS::NS;
     const R T = (R)T_, rtol = (R)rtol_, atol = (R)atol_;
-    constexpr R a21 = 1.0 / 5;
-    constexpr R a31 = 3.0 / 40, a32 = 9.0 / 40;
-    constexpr R a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
-    constexpr R a51 = -11.0 / 54, a52 = 5.0 / 2, a53 = -70.0 / 27, a54 = 35.0 / 27;
-    constexpr R a61 = 1631.0 / 55296, a62 = 175.0 / 512, a63 = 575.0 / 13824, a64 = 44275.0 / 110592, a65 = 253.0 / 4096;
-    constexpr R b1 = 37.0 / 378, b3 = 250.0 / 621, b4 = 125.0 / 594, b6 = 512.0 / 1771;
-    constexpr R e1 = 37.0 / 378 - 2825.0 / 27648, e3 = 250.0 / 621 - 18575.0 / 48384,
-                     e4 = 125.0 / 594 - 13525.0 / 55296, e5 = -277.0 / 14336, e6 = 512.0 / 1771 - 1.0 / 4;
-
+    R a21 = 1.0 / 5;
+    R a31 = 3.0 / 40, a32 = 9.0 / 40;
+    R a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
+    R a51 = -11.0 / 54, a52 = 5.0 / 2, a53 = -70.0 / 27, a54 = 35.0 / 27;
+    R a61 = 1631.0 / 55296, a62 = 175.0 / 512, a63 = 575.0 / 13824, a64 = 44275.0 / 110592, a65 = 253.0 / 4096;
+    R b1 = 37.0 / 378, b3 = 250.0 / 621, b4 = 125.0 / 594, b6 = 512.0 / 1771;
+    R e1 = 37.0 / 378 - 2825.0 / 27648, e3 = 250.0 / 621 - 18575.0 / 48384,
+      e4 = 125.0 / 594 - 13525.0 / 55296, e5 = -277.0 / 14336, e6 = 512.0 / 1771 - 1.0 / 4;
+    // Keep the tableau in scalar registers across the attempt loop.  Left alone, the compiler re-materialises each 64-bit
+    // literal with two s_mov_b32 right before its use -- free when other waves fill the issue slots, but this kernel runs
+    // one wave per SIMD, where every scalar instruction costs a full slot (tools/micro/valu_rates.hip: 2.6 ns, the price of
+    // an fp64 FMA).  Passing the values through an empty asm with an "s" operand makes them opaque: -1.4 % kernel time.
+#define SP_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
+    SP_KEEP_SCALAR(a21); SP_KEEP_SCALAR(a31); SP_KEEP_SCALAR(a32); SP_KEEP_SCALAR(a41); SP_KEEP_SCALAR(a42); SP_KEEP_SCALAR(a43);
+    SP_KEEP_SCALAR(a51); SP_KEEP_SCALAR(a52); SP_KEEP_SCALAR(a53); SP_KEEP_SCALAR(a54);
+    SP_KEEP_SCALAR(a61); SP_KEEP_SCALAR(a62); SP_KEEP_SCALAR(a63); SP_KEEP_SCALAR(a64); SP_KEEP_SCALAR(a65);
+    SP_KEEP_SCALAR(b1); SP_KEEP_SCALAR(b3); SP_KEEP_SCALAR(b4); SP_KEEP_SCALAR(b6);
+    SP_KEEP_SCALAR(e1); SP_KEEP_SCALAR(e3); SP_KEEP_SCALAR(e4); SP_KEEP_SCALAR(e5); SP_KEEP_SCALAR(e6);
+#undef SP_KEEP_SCALAR
     R t = 0, h = (R)h_carry;
     if (!(h > (R)0) || h > T) h = T;
-    int attempts = 0;
+    // attempts made today by every lane that is still alive: lanes attempt in lockstep (one attempt per trip of the loop
+    // below for everyone who has not finished), so one wave-uniform counter serves them all -- and the step cap and the
+    // resync schedule derived from it are scalar branches
+    int trip = 0;
     bool alive = true;
     // a member whose state is already non-finite is not integrated further
 #pragma unroll
@@ -438,7 +451,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         const R rem = T - t;
         R hh = h;
         if (rem <= (R)1.1 * h) hh = rem; else if (rem < (R)2 * h) hh = (R)0.5 * rem;
-        const bool last_chance = (attempts + 1 >= max_steps);
+        const bool last_chance = (trip + 1 >= max_steps);
         if (last_chance) hh = rem;
         if (!alive) hh = 0;
 
@@ -520,33 +533,23 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         // v_max_f64 drops NaNs, so the finiteness test is on the increment itself
         const bool bad = !(err < sp_huge<R>()) || !(sp_abs(chk) < sp_huge<R>());
 
-        bool accept = false, give_up = false;
-        if (alive) {
-            ++attempts;
-            cnt.rhs += 6;
-            if (last_chance) cnt.capped = true;
-            give_up = bad && (last_chance || hh <= (R)1.0e-9 * T);
-            accept = !bad && (err <= (R)1 || last_chance);
-            if (accept) {
-                t = (hh == rem) ? T : t + hh;
-                ++cnt.steps;
-            } else if (!give_up) {
-                ++cnt.rejected;
-            }
-            float fac;
-            if (bad) fac = 0.2f;
-            else if (err == (R)0) fac = 5.0f;
-            else {
-                // 0.9 err^(-1/5) in fp32 (v_log_f32 / v_exp_f32): a step-size factor needs no more
-                fac = 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f((float)err));
-                fac = fminf(fmaxf(fac, 0.2f), 5.0f);
-            }
-            h = hh * (R)fac;
-        }
+        ++trip;
+        // 0.9 err^(-1/5) in fp32 (v_log_f32 / v_exp_f32): a step-size factor needs no more.  err == 0 gives +inf -> 5;
+        // err == inf gives 0 -> 0.2 (err is never NaN: v_max_f64 drops NaNs).
+        float fac = 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f((float)err));
+        fac = fminf(fmaxf(fac, 0.2f), 5.0f);
+        const bool accept = alive && !bad && (err <= (R)1 || last_chance);
+        bool give_up = false;
+        cnt.rhs += alive ? 6u : 0u;
+        cnt.steps += accept ? 1u : 0u;
+        if (last_chance && alive) cnt.capped = true;
+        t = accept ? ((hh == rem) ? T : t + hh) : t;
         // State update in place: y += m dy with m = 1 for lanes that accepted, 0 otherwise (no copies of the
         // state through the loop).  0 * NaN would poison a lane that merely rejected a non-finite trial, so the
-        // rare wave that has such a lane takes the select path instead.
+        // rare wave that has such a lane takes the select path instead; that is also where a lane gives up.
         if (__any(alive && bad)) {
+            give_up = alive && bad && (last_chance || hh <= (R)1.0e-9 * T);
+            if (alive && bad) fac = 0.2f;
 #pragma unroll
             for (int i = 0; i < NS; ++i) y[i] = give_up ? (R)__builtin_nanf("") : (accept ? y[i] + dy[i] : y[i]);
 #pragma unroll
@@ -559,14 +562,14 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 #pragma unroll
             for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma((double)m, (double)dq[i], yq[i]);
         }
+        cnt.rejected += (alive && !accept && !give_up) ? 1u : 0u;
+        h = alive ? hh * (R)fac : h;
         alive = alive && !give_up && (t < T);
         if (SYS::RESYNC_EVERY > 0) {
-            // after every RESYNC_EVERY-th attempt of the day.  Every lane that is still alive has made the same number of
-            // attempts (one per trip), so the branch is wave-uniform while the schedule stays a function of the lane's
-            // own history: results do not depend on which members share a wavefront.
-            const bool due = alive && (attempts % SYS::RESYNC_EVERY) == 0;
-            if (__any(due)) {
-                if (due) SYS::resync(y, c);
+            // after every RESYNC_EVERY-th attempt of the day: a wave-uniform test (see `trip`), while the schedule stays a
+            // function of the lane's own history -- results do not depend on which members share a wavefront
+            if ((trip % SYS::RESYNC_EVERY) == 0) {
+                if (alive) SYS::resync(y, c);
             }
         }
     }

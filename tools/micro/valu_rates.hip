@@ -1,0 +1,88 @@
+// Issue cost of the instructions the time-stepping kernel leans on, measured the way that kernel runs: ONE wave per SIMD
+// (1024 single-wave workgroups), 16 independent chains, 64 instructions per loop trip.  Prints cycles per wave64 instruction.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/valu_rates.hip -o tools/micro/valu_rates && tools/micro/valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+enum { FMA64, MUL64, ADD64, MAX64, MIN64, RCP64, CMPSEL64, CVT6432, FMA32, RCP32, EXP32, LOG32, FMA64_SMOV2, FMA64_SNOP, N_OPS };
+
+template <int OP>
+__global__ __launch_bounds__(64, 1) void k(double* out, long long* cyc, int iters, double seed)
+{
+    double a[16];
+    float f[16];
+    for (int i = 0; i < 16; ++i) { a[i] = seed + threadIdx.x * 1e-3 + i * 0.01; f[i] = (float)a[i]; }
+    const double c1 = seed * 0.666, c2 = seed * 1e-9;
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (OP == FMA64) a[i] = __builtin_fma(a[i], c1, c2);
+                if (OP == MUL64) a[i] = a[i] * c1;
+                if (OP == ADD64) a[i] = a[i] + c2;
+                if (OP == MAX64) a[i] = __builtin_fmax(a[i], a[(i + 1) & 15]);
+                if (OP == MIN64) a[i] = __builtin_fmin(a[i], a[(i + 1) & 15]);
+                if (OP == RCP64) a[i] = __builtin_amdgcn_rcp(a[i]);
+                if (OP == CMPSEL64) a[i] = (a[i] > a[(i + 1) & 15]) ? a[i] : c1;           // v_cmp + 2 v_cndmask
+                if (OP == CVT6432) f[i] = (float)a[i];                                       // (dead-code proof below)
+                if (OP == FMA32) f[i] = __builtin_fmaf(f[i], 0.999f, 1e-3f);
+                if (OP == RCP32) f[i] = __builtin_amdgcn_rcpf(f[i]);
+                if (OP == EXP32) f[i] = __builtin_amdgcn_exp2f(f[i]);
+                if (OP == LOG32) f[i] = __builtin_amdgcn_logf(f[i]);
+                if (OP == FMA64_SMOV2) { a[i] = __builtin_fma(a[i], c1, c2); asm volatile("s_mov_b32 s40, 0x1234\n\ts_mov_b32 s41, 0x5678" ::: "s40", "s41"); }
+                if (OP == FMA64_SNOP) { a[i] = __builtin_fma(a[i], c1, c2); asm volatile("s_nop 0"); }
+                if (OP == CVT6432) a[i] += 1.0;                                              // keeps the conversions distinct: + v_add_f64
+            }
+    }
+    const long long t1 = clock64();
+    double s = 0;
+    for (int i = 0; i < 16; ++i) s += a[i] + f[i];
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int OP>
+int run(const char* name, double* out, long long* cyc, double fma_ref)
+{
+    const int blocks = 1024, iters = 4000;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, out, cyc, iters, 1.5);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    const double ns = ms * 1e6 / iters / 64;
+    printf("%-34s %6.2f ns per trip-instruction%s\n", name, ns, fma_ref > 0 ? "" : "");
+    return 0;
+}
+
+int main()
+{
+    double* out; long long* cyc;
+    CHECK(hipMalloc(&out, 1024 * 64 * sizeof(double)));
+    CHECK(hipMalloc(&cyc, 1024 * sizeof(long long)));
+    int dev = 0; hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, dev));
+    printf("%s, %d CUs, clock %.0f MHz (1 cycle = %.3f ns at that clock)\n", p.name, p.multiProcessorCount, p.clockRate / 1e3, 1e6 / p.clockRate);
+    run<FMA64>("v_fma_f64", out, cyc, 0);
+    run<MUL64>("v_mul_f64", out, cyc, 0);
+    run<ADD64>("v_add_f64", out, cyc, 0);
+    run<MAX64>("v_max_f64", out, cyc, 0);
+    run<MIN64>("v_min_f64", out, cyc, 0);
+    run<RCP64>("v_rcp_f64", out, cyc, 0);
+    run<CMPSEL64>("v_cmp_gt_f64 + 2 v_cndmask_b32", out, cyc, 0);
+    run<CVT6432>("v_cvt_f32_f64 + v_add_f64", out, cyc, 0);
+    run<FMA32>("v_fma_f32", out, cyc, 0);
+    run<RCP32>("v_rcp_f32", out, cyc, 0);
+    run<EXP32>("v_exp_f32", out, cyc, 0);
+    run<LOG32>("v_log_f32", out, cyc, 0);
+    run<FMA64_SMOV2>("v_fma_f64 + 2 s_mov_b32", out, cyc, 0);
+    run<FMA64_SNOP>("v_fma_f64 + s_nop 0", out, cyc, 0);
+    return 0;
+}
