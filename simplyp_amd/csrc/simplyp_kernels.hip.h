@@ -429,6 +429,8 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     SP_KEEP_SCALAR(a61); SP_KEEP_SCALAR(a62); SP_KEEP_SCALAR(a63); SP_KEEP_SCALAR(a64); SP_KEEP_SCALAR(a65);
     SP_KEEP_SCALAR(b1); SP_KEEP_SCALAR(b3); SP_KEEP_SCALAR(b4); SP_KEEP_SCALAR(b6);
     SP_KEEP_SCALAR(e1); SP_KEEP_SCALAR(e3); SP_KEEP_SCALAR(e4); SP_KEEP_SCALAR(e5); SP_KEEP_SCALAR(e6);
+    R huge = sp_huge<R>(), c11 = (R)1.1;
+    SP_KEEP_SCALAR(huge); SP_KEEP_SCALAR(c11);
 #undef SP_KEEP_SCALAR
     R t = 0, h = (R)h_carry;
     if (!(h > (R)0) || h > T) h = T;
@@ -450,7 +452,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         ++cnt.wave_trips;                 // one attempt issued for the whole wavefront, whoever still needs it
         const R rem = T - t;
         R hh = h;
-        if (rem <= (R)1.1 * h) hh = rem; else if (rem < (R)2 * h) hh = (R)0.5 * rem;
+        if (rem <= c11 * h) hh = rem; else if (rem < (R)2 * h) hh = (R)0.5 * rem;
         const bool last_chance = (trip + 1 >= max_steps);
         if (last_chance) hh = rem;
         if (!alive) hh = 0;
@@ -531,12 +533,14 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
             }
         }
         // v_max_f64 drops NaNs, so the finiteness test is on the increment itself
-        const bool bad = !(err < sp_huge<R>()) || !(sp_abs(chk) < sp_huge<R>());
+        const bool bad = !(err < huge) || !(sp_abs(chk) < huge);
 
         ++trip;
         // 0.9 err^(-1/5) in fp32 (v_log_f32 / v_exp_f32): a step-size factor needs no more.  err == 0 gives +inf -> 5;
         // err == inf gives 0 -> 0.2 (err is never NaN: v_max_f64 drops NaNs).
-        float fac = 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f((float)err));
+        // (raw v_log_f32 / v_exp_f32: the library versions add denormal-range fix-ups, ~12 instructions, for arguments
+        // whose factor is clamped to 5 anyway)
+        float fac = 0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
         fac = fminf(fmaxf(fac, 0.2f), 5.0f);
         const bool accept = alive && !bad && (err <= (R)1 || last_chance);
         bool give_up = false;
