@@ -461,7 +461,8 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         ++cnt.wave_trips;                 // one attempt issued for the whole wavefront, whoever still needs it
         const R rem = T - t;
         R hh = h;
-        if (rem <= c11 * h) hh = rem; else if (rem < (R)2 * h) hh = (R)0.5 * rem;
+        hh = (rem < (R)2 * h) ? (R)0.5 * rem : hh;      // (selects, not branches: the loop is long enough without them)
+        hh = (rem <= c11 * h) ? rem : hh;
         const bool last_chance = (trip + 1 >= max_steps);
         if (last_chance) hh = rem;
         if (!alive) hh = 0;
