@@ -350,6 +350,31 @@ def test_full_size_monte_carlo_properties(engine0, oracle_lib):
     assert helpers.max_rel_err(o2[0, :, 0, :], inv) < 1e-12
 
 
+def test_one_million_members_on_one_gpu(engine0):
+    """BASELINE config C5's ensemble size on a single GPU (5.5 years, annual sums of two columns so that the output stays
+    small): 15 625 member groups through the task queue, cost-ordered; no member flagged, every member in exactly one slot,
+    and a slice of members run on its own equals the big run bit for bit."""
+    import torch
+    E = 1000000
+    pr = synthetic.c3_problem(E, end_dt='1986-06-30', solver=dict(out_slot_order=1), out_mask=marshal.mask_of_columns(['Qr', 'TDP_kg/day']))
+    periods, pod = np.unique(pr['met'].index.year.values, return_inverse=True)
+    pod = np.ascontiguousarray(pod, dtype=np.int32)
+    pr['opts'].n_periods = len(periods)
+    out, status, st = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], pr['opts'],
+                                  period_of_day=pod)
+    assert st['queued'] == 1 and st['balanced'] == 1 and int((status != 0).sum()) == 0 and bool(torch.isfinite(out).all())
+    mos = st['member_of_slot']
+    assert int(torch.unique(mos).numel()) == E and int(mos.min()) == 0 and int(mos.max()) == E - 1
+    pick = np.arange(0, E, 9973)[:64]
+    sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
+    sub['opts'].out_slot_order = 0
+    alone = engine0.run(sub['forcing'], sub['doy'], sub['member_params'], sub['reach_params'], sub['up_ptr'], sub['up_idx'], sub['opts'],
+                        period_of_day=pod)[0]
+    slot_of = torch.empty(E, dtype=torch.long, device=out.device)
+    slot_of[mos.long()] = torch.arange(E, device=out.device)
+    assert bool(torch.equal(out[..., slot_of[torch.as_tensor(pick, device=out.device)]], alone))
+
+
 def test_load_balancer_groups_members_with_similar_step_patterns(engine0):
     """What the pilot + ordering is for: lanes of a wavefront that need similar step counts day by day.  On the bench's
     Monte-Carlo distribution the fraction of issued lane-attempts that were needed (stats.simt_efficiency) rises from
