@@ -125,6 +125,14 @@ __device__ __forceinline__ double sp_rcp(double x)
 // log(x) for normal x > 0.  x = 2^k (1+f), sqrt(1/2) < 1+f <= sqrt(2); s = f/(2+f);
 // log(1+f) = f - hfsq + s (hfsq + R(s^2)), R = the classic degree-7 even minimax polynomial
 // (fdlibm e_log.c coefficients Lg1..Lg7).
+// One Newton step on v_rcp_f64 (raw: 4.6e-8 relative, one step: 2e-15, two: correctly rounded -- tools/micro/rcp_accuracy.hip).
+// Enough for the derivatives of the auxiliary states, which are re-evaluated exactly every few steps anyway.
+__device__ __forceinline__ double sp_rcp1(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ double sp_log(double x)
 {
     double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
@@ -331,7 +339,7 @@ struct SysAug {
         dz[6] = __builtin_fma(c.cPP, pk, c.PPrUS) - oP;                               // :171-178
         dz[7] = -c.mu * z[7] * dz[0];                                                 // d exp(-mu VsA)
         dz[8] = -c.mu * z[8] * dz[1];
-        const double r = dQr * sp_rcp(Qr);
+        const double r = dQr * sp_rcp1(Qr);
         dz[9] = c.bQ * pb * r;                                                        // d Qr**b_Q
         dz[10] = c.kM * pk * r;                                                       // d Qr**k_M
         q[0] = Qr; q[1] = oM; q[2] = oT; q[3] = oP;                                   // :132,:147,:168,:180
