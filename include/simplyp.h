@@ -105,7 +105,7 @@ typedef struct {
 typedef struct {
     int32_t  integrator;     /* simplyp_integrator                                         */
     int32_t  substeps;       /* RK4: steps per day.  Cash-Karp: first trial step = step_len/substeps */
-    double   rtol;           /* Cash-Karp: err_i <= atol + rtol*max(|y_i|,|ynew_i|)        */
+    double   rtol;           /* Cash-Karp: err_i <= atol + rtol*max(|y_i|,|y_i + h k1_i|)  */
     double   atol;
     int32_t  max_steps;      /* Cash-Karp: attempted steps per day before SIMPLYP_STATUS_STEPCAP */
     int32_t  dynamic_epc0;   /* dynamic_options['Dynamic_EPC0'] == 'y'  (model.py:600,684) */

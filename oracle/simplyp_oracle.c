@@ -208,7 +208,10 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
             double inc = 0.0, ee = 0.0;
             for (int s = 0; s < 6; ++s) { inc += CK_B[s] * k[s][i]; ee += CK_E[s] * k[s][i]; }
             yn[i] = y[i] + hh * inc;
-            double sc = atol + rtol * fmax(fabs(y[i]), fabs(yn[i]));
+            /* scale: the state and its Euler predictor (the kernel forms the 5th-order increment only for accepted steps);
+             * the four daily integrals (5, 7, 9, 11), accumulated outside the stages there, use their new value */
+            const int is_quad = (i == 5 || i == 7 || i == 9 || i == 11);
+            double sc = atol + rtol * fmax(fabs(y[i]), is_quad ? fabs(yn[i]) : fabs(y[i] + hh * k[0][i]));
             double r = fabs(hh * ee) / sc;
             if (r > err) err = r;                 /* NaN terms drop out, like v_max_f64 */
         }
@@ -332,7 +335,7 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
             for (int s = 0; s < 6; ++s) { inc += CK_B[s] * k[s][i]; ee += CK_E[s] * k[s][i]; }
             zn[i] = z[i] + hh * inc;
             if (i >= AUG_NERR) continue;          /* error norm: the 7 physical states only (see below) */
-            double sc = atol + rtol * fmax(fabs(z[i]), fabs(zn[i]));
+            double sc = atol + rtol * fmax(fabs(z[i]), fabs(z[i] + hh * k[0][i]));      /* Euler predictor, as in the kernel */
             double r = fabs(hh * ee) / sc;
             if (r > err) err = r;
         }

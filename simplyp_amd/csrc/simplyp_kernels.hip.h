@@ -524,23 +524,18 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(b6, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e6, kq[i], eq[i]); }
 
-        // increment of the 5th-order solution, embedded error estimate, scaled error norm
+        // embedded error estimate and scaled error norm.  The scale uses the Euler predictor y + h k1 for "the new value":
+        // the 5th-order increment itself is only formed once the step is accepted (weights premultiplied by the accept mask).
         R err = 0, chk = 0;
-        R dy[NS], dq[4];
-        const R hb1 = hh * b1, hb3 = hh * b3, hb4 = hh * b4, hb6 = hh * b6;
+        R dq[4];
         const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            dy[i] = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], hb1 * k1[i])));
-            // A non-finite value anywhere shows up in the increments of the reach states within the same attempt: soil water
-            // and groundwater feed the reach flow (k[3]), Qr**k_M feeds the sediment (k[4]); only the two P masses are on
-            // their own.  (Augmented layout: 3..6 = Qr Msus TDPr PPr; literal layout: 4..7.)
-            if (i >= NS - (NS == 11 ? 8 : 4) && i < NS - (NS == 11 ? 4 : 0)) chk += dy[i];
             if (i < SYS::N_ERR) {
-                const R yn = y[i] + dy[i];
                 const R he = sp_fma(he1, k1[i], sp_fma(he3, k3[i], sp_fma(he4, k4[i],
                                   sp_fma(he5, k5[i], he6 * k6[i]))));
-                const R sc = sp_fma(rtol, sp_absmax(y[i], yn), atol);
+                if (i >= NS - (NS == 11 ? 8 : 4) && i < NS - (NS == 11 ? 4 : 0)) chk += he;
+                const R sc = sp_fma(rtol, sp_absmax(y[i], sp_fma(hh, k1[i], y[i])), atol);
                 err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
             }
         }
@@ -569,23 +564,30 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         cnt.steps += accept ? 1u : 0u;
         if (last_chance && alive) cnt.capped = true;
         t = accept ? ((hh == rem) ? T : t + hh) : t;
-        // State update in place: y += m dy with m = 1 for lanes that accepted, 0 otherwise (no copies of the
-        // state through the loop).  0 * NaN would poison a lane that merely rejected a non-finite trial, so the
-        // rare wave that has such a lane takes the select path instead; that is also where a lane gives up.
+        // State update in place, only for lanes that accepted: y += (m h b1) k1 + (m h b3) k3 + (m h b4) k4 + (m h b6) k6 with
+        // m = 1 / 0.  0 * NaN would poison a lane that merely rejected a non-finite trial, so the rare wave that has such
+        // a lane takes the select path instead; that is also where a lane gives up.
         if (__any(alive && bad)) {
             give_up = alive && bad && (last_chance || hh <= (R)1.0e-9 * T);
             if (alive && bad) fac = 0.2f;
+            const R hb1 = hh * b1, hb3 = hh * b3, hb4 = hh * b4, hb6 = hh * b6;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) y[i] = give_up ? (R)__builtin_nanf("") : (accept ? y[i] + dy[i] : y[i]);
+            for (int i = 0; i < NS; ++i) {
+                // (the same expression as on the common path, so that a member's result does not depend on its wave mates)
+                const R yn = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], sp_fma(hb1, k1[i], y[i]))));
+                y[i] = give_up ? (R)__builtin_nanf("") : (accept ? yn : y[i]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) yq[i] = give_up ? __builtin_nan("") : (accept ? yq[i] + (double)dq[i] : yq[i]);
             if (give_up) { cnt.poisoned = true; }
         } else {
-            const R m = accept ? (R)1 : (R)0;
+            const R m = accept ? hh : (R)0;
+            const R hb1 = m * b1, hb3 = m * b3, hb4 = m * b4, hb6 = m * b6;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) y[i] = sp_fma(m, dy[i], y[i]);
+            for (int i = 0; i < NS; ++i) y[i] = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], sp_fma(hb1, k1[i], y[i]))));
+            const R mq = accept ? (R)1 : (R)0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma((double)m, (double)dq[i], yq[i]);
+            for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma((double)mq, (double)dq[i], yq[i]);
         }
         cnt.rejected += (alive && !accept && !give_up) ? 1u : 0u;
         h = alive ? hh * (R)fac : h;
