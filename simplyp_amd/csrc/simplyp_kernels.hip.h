@@ -455,6 +455,8 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     // below for everyone who has not finished), so one wave-uniform counter serves them all -- and the step cap and the
     // resync schedule derived from it are scalar branches
     int trip = 0;
+    unsigned n_alive = 0, n_acc = 0;       // this lane's attempts and accepted steps today (the counters are settled after the loop)
+    bool gave_up_today = false;
     bool alive = true;
     // a member whose state is already non-finite is not integrated further
 #pragma unroll
@@ -560,8 +562,8 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         fac = fminf(fmaxf(fac, 0.2f), 5.0f);
         const bool accept = alive && !bad && (err <= (R)1 || last_chance);
         bool give_up = false;
-        cnt.rhs += alive ? 6u : 0u;
-        cnt.steps += accept ? 1u : 0u;
+        n_alive += alive ? 1u : 0u;
+        n_acc += accept ? 1u : 0u;
         if (last_chance && alive) cnt.capped = true;
         t = accept ? ((hh == rem) ? T : t + hh) : t;
         // State update in place, only for lanes that accepted: y += (m h b1) k1 + (m h b3) k3 + (m h b4) k4 + (m h b6) k6 with
@@ -579,7 +581,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) yq[i] = give_up ? __builtin_nan("") : (accept ? yq[i] + (double)dq[i] : yq[i]);
-            if (give_up) { cnt.poisoned = true; }
+            if (give_up) { cnt.poisoned = true; gave_up_today = true; }
         } else {
             const R m = accept ? hh : (R)0;
             const R hb1 = m * b1, hb3 = m * b3, hb4 = m * b4, hb6 = m * b6;
@@ -589,7 +591,6 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 #pragma unroll
             for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma((double)mq, (double)dq[i], yq[i]);
         }
-        cnt.rejected += (alive && !accept && !give_up) ? 1u : 0u;
         h = alive ? hh * (R)fac : h;
         alive = alive && !give_up && (t < T);
         if (SYS::RESYNC_EVERY > 0) {
@@ -600,6 +601,10 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
             }
         }
     }
+    // every attempt of a lane ends accepted, rejected, or -- at most once, then the lane is dead -- given up
+    cnt.rhs += 6u * n_alive;
+    cnt.steps += n_acc;
+    cnt.rejected += n_alive - n_acc - (gave_up_today ? 1u : 0u);
     h_carry = (double)h;
 }
 
