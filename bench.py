@@ -27,9 +27,9 @@ FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64
 BYTES_PER_CD_REACH5 = 56         # 5 outputs x 8 B written + 2 forcing values x 8 B read per catchment-day
 MEMBERS_PER_GPU = 100000
 # fp64 operations of one Cash-Karp attempt of one member on the augmented system (6 right-hand sides + stage sums + error
-# norm + update), counted in the gfx950 ISA of simplyp_queue_kernel<2,false>'s attempt loop (common path): 374 FMAs (x2) +
-# 234 mul + 92 add + 14 max + 13 rcp (Roofline)
-FLOPS_PER_ATTEMPT = 2 * 374 + 234 + 92 + 14 + 13
+# norm + update), counted in the gfx950 ISA of simplyp_queue_kernel<2,false>'s attempt loop (common path): 369 FMAs (x2) +
+# 223 mul + 76 add + 14 max + 13 rcp (Roofline)
+FLOPS_PER_ATTEMPT = 2 * 369 + 223 + 76 + 14 + 13
 
 
 def main():
