@@ -174,7 +174,8 @@ static int state_finite(const double* y)
  *   a day whose start state is non-finite is not integrated (member poisoned);
  *   trial step hh = h, except  rem <= 1.1 h -> hh = rem;  rem < 2 h -> hh = rem/2   (rem = T - t);
  *   the max_steps-th attempt of a day takes hh = rem and is accepted whatever its error (STEPCAP);
- *   err = max_i |hh e_i| / (atol + rtol * max(|y_i|, |ynew_i|)) over all 12 components;
+ *   err = max_i |hh e_i| / (atol + rtol * max(|y_i|, |y_i + hh k1_i|)) over all 12 components (Euler predictor in the
+ *   scale; the four daily integrals use their new value);
  *   a non-finite trial is rejected with factor 0.2; at hh <= 1e-9 T (or on the last attempt) the
  *   member is poisoned (state := NaN) instead;
  *   accept iff err <= 1;  h <- hh * clamp(0.9 * err^(-1/5), 0.2, 5)   (err == 0 -> 5);
