@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- catchment-days/s of the SimplyP time-stepping engine on MI355X.
 
-Workload (config.workload): BASELINE.json's Tarland Monte-Carlo parameter ensemble (config C3): the shipped
-Tarland workbook + 30-year daily met series (1981-2010, 10 957 days, 1 sub-catchment, Dynamic_EPC0 = 'y'),
-100 000 members per GPU drawn from SURVEY.md section 8(d)'s distribution (seed 20240601 + rank), the five
-documented reach outputs written daily ("REACH-5": Vr, Qr, and the three daily fluxes), fp64, default solver
-(Cash-Karp 5(4), rtol 1e-8: the setting that meets the <= 1e-6 parity bar against odeint(rtol=atol=1e-12)).
-A "step" is one pass of the whole ensemble through all days; inputs are resident in HBM before the timed
-region.  Members shard across GPUs with no data-path collective (weak scaling: every rank integrates its own
-100 000 members); the only exchange is the final gather of per-member summaries to rank 0 over RCCL.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4|c5] [--scaling weak|strong]
 
-Prints ONE JSON line on rank 0.
+Default workload (config.workload): BASELINE.json's Tarland Monte-Carlo parameter ensemble (config C3): the shipped
+Tarland workbook + 30-year daily met series (1981-2010, 10 957 days, 1 sub-catchment, Dynamic_EPC0 = 'y'),
+100 000 members per GPU drawn from SURVEY.md section 8(d)'s distribution, the five documented reach outputs written
+daily ("REACH-5": Vr, Qr and the three daily fluxes), fp64, default solver (Cash-Karp 5(4), rtol 1e-8: the setting that
+meets the <= 1e-6 parity bar against odeint(rtol=atol=1e-12)).
+
+A "step" is one pass of the whole ensemble through all days.  Inputs are resident in HBM before the timed region; the
+output table is DELIVERED TO PINNED HOST MEMORY inside it (the reference produces its values in host memory,
+model.py:644, :721-724): the library streams every finished 256-day chunk over PCIe on a second stream while later chunks
+compute (simplyp_stream_out), and the step ends when the last byte has arrived and rank 0 holds the per-member
+summaries.  `value` is that transfer-inclusive rate; `value_device_resident` (table left in HBM) and
+`value_h2d_inclusive` (plus the upload of the inputs) are reported beside it.
+
+Members shard across GPUs with no data-path collective (ensemble.run_sharded); the only exchange is the final gather of
+per-member summaries to rank 0 over RCCL.  --scaling weak (default): every rank brings its own `--members`; strong: one
+ensemble of `--members` split over the ranks.
+
+With --gpus N > 1 from a plain shell the script starts its own N ranks (torch.distributed.run) before anything touches
+the GPU and relays rank 0's line.  Prints ONE JSON line on rank 0.
 """
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,23 +37,101 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64
-BYTES_PER_CD_REACH5 = 56         # 5 outputs x 8 B written + 2 forcing values x 8 B read per catchment-day
-MEMBERS_PER_GPU = 100000
+PCIE_SPEC_GBS = 63.0             # PCIe Gen5 x16, same guide
 # fp64 operations of one Cash-Karp attempt of one member on the augmented system (6 right-hand sides + stage sums + error
 # norm + update), counted in the gfx950 ISA of simplyp_queue_kernel<2,false>'s attempt loop (common path): 369 FMAs (x2) +
 # 223 mul + 76 add + 14 max + 13 rcp (Roofline)
 FLOPS_PER_ATTEMPT = 2 * 369 + 223 + 76 + 14 + 13
 
+# BASELINE.json's configurations.  bytes_per_cd: algorithmic HBM bytes per catchment-day of the
+# config's output mode -- FULL = 25 outputs x 8 B + 2 forcing values x 8 B; REACH-5 = 5 x 8 + 16; annual sums = 16 B of
+# forcing + 4 columns x 8 B x 30 rows / 10 957 days.
+CONFIGS = {
+    'c3': dict(members=100000, bytes_per_cd=56.0, dtype='f64', out='REACH-5 daily', parity_grade=True,
+               what="Tarland Monte-Carlo parameter ensemble (BASELINE config C3): 1 sub-catchment, 2 land-use soil boxes, "
+                    "30-yr daily 1981-2010 (10957 d), Cash-Karp 5(4) on the augmented system, rtol=1e-8"),
+    'c2': dict(members=1024, bytes_per_cd=216.0, dtype='f64', out='FULL 25 columns daily', parity_grade=True,
+               what="Tarland full catchment, replicated-parameter ensemble (BASELINE config C2): 1 sub-catchment, 30-yr daily "
+                    "1981-2010 (10957 d), all 25 output columns, Cash-Karp 5(4) on the augmented system, rtol=1e-8"),
+    'c4': dict(members=10000, bytes_per_cd=56.0, dtype='f64', out='REACH-5 daily of the outlet reach', parity_grade=True,
+               what="synthetic 256-reach chain x 4 land-use classes, 50-yr daily (18262 d), reach-chain routing in-kernel "
+                    "(BASELINE config C4), Cash-Karp 5(4) on the augmented system, rtol=1e-8"),
+    'c5': dict(members=125000, bytes_per_cd=16.0 + 4 * 8 * 30 / 10957.0, dtype='f32+f64', out='annual sums of the 4 fluxes',
+               parity_grade=False,
+               what="one GPU's share of the 1M-member Tarland ensemble (BASELINE config C5): fp32 Runge-Kutta stages + fp64 "
+                    "daily integrals / soil P / carried state, rtol=1e-5, output = 30 annual sums of Qr and the 3 fluxes"),
+}
 
-def main():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--members', type=int, default=MEMBERS_PER_GPU, help='members per GPU')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='c3')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--members', type=int, default=None,
+                    help='members per GPU (weak) or in the whole ensemble (strong); default: the config\'s size')
+    ap.add_argument('--reaches', type=int, default=256, help='c4 only')
+    ap.add_argument('--days', type=int, default=None, help='c4 only (default 18262)')
+    ap.add_argument('--no-stream', action='store_true', help='leave the output table in HBM (value = device-resident rate)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-parity', action='store_true', help='skip the accuracy check (keeps a profile to one kernel shape)')
-    args = ap.parse_args()
+    ap.add_argument('--no-parity', action='store_true', help='skip the accuracy checks (keeps a profile to one kernel shape)')
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """--gpus N > 1 from a plain shell: start N ranks with torch.distributed.run as a CHILD process (nothing in this
+    process has touched the GPU yet) and relay its output; exit with its code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_source_hash():
+    """sha256 over the sources the kernels are built from: profiles/traffic.json is only valid for the build it was
+    measured on."""
+    h = hashlib.sha256()
+    for rel in ('simplyp_amd/csrc/simplyp_kernels.hip.h', 'simplyp_amd/csrc/simplyp_hip.hip',
+                'simplyp_amd/csrc/simplyp_gof.hip.h', 'include/simplyp.h'):
+        with open(os.path.join(ROOT, rel), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_problem(cfg, n_members, seed_offset, args):
+    from simplyp_amd import marshal, synthetic
+    import numpy as np
+    if cfg == 'c3':
+        pr = synthetic.c3_problem(n_members, seed=synthetic.C3_SEED + seed_offset, solver=dict(out_slot_order=1))
+    elif cfg == 'c2':
+        pr = synthetic.c3_problem(n_members, solver=dict(out_slot_order=1), out_mask=marshal.MASK_ALL, replicated=True)
+    elif cfg == 'c4':
+        pr = synthetic.c4_problem(n_members, n_reaches=args.reaches, n_days=args.days or 18262,
+                                  seed=synthetic.C4_SEED + seed_offset, solver=dict(out_slot_order=1))
+    else:
+        fluxes = ['Qr', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day']
+        pr = synthetic.c3_problem(n_members, seed=20240603 + seed_offset, out_mask=marshal.mask_of_columns(fluxes),
+                                  solver=dict(integrator='cashkarp_aug_f32', rtol=1e-5, atol=1e-7, out_slot_order=1))
+        years = pr['met'].index.year.values
+        periods, pod = np.unique(years, return_inverse=True)
+        pr['opts'].n_periods = len(periods)
+        pr['period_of_day'] = np.ascontiguousarray(pod, dtype=np.int32)
+    pr.setdefault('out_reaches', None)
+    pr.setdefault('period_of_day', None)
+    return pr
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
 
     import numpy as np
     import torch
@@ -50,8 +141,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
-                         % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # one rank per GPU; SIMPLYP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     backend = os.environ.get('SIMPLYP_BENCH_BACKEND', 'nccl')
     n_dev = torch.cuda.device_count()
@@ -65,103 +155,233 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from simplyp_amd import engine, ensemble, marshal, synthetic
+    from simplyp_amd import engine, ensemble, marshal
 
-    E = args.members
-    # outputs stay in lane-slot order (fully coalesced stores) + the member id of every slot: what a consumer of a
-    # load-balanced run gets; the per-member summaries below are put back into member order before the gather
-    prob = synthetic.c3_problem(E, seed=synthetic.C3_SEED + rank, solver=dict(out_slot_order=1))
+    cfg = CONFIGS[args.config]
+    n_arg = args.members if args.members is not None else cfg['members']
+    if args.scaling == 'weak':
+        e_local, e_total = n_arg, n_arg * world
+        prob = build_problem(args.config, e_local, rank, args)
+    else:
+        e_total = n_arg
+        lo, hi = ensemble.shard_bounds(e_total, world, rank)
+        e_local = hi - lo
+        prob = build_problem(args.config, e_total, 0, args)          # the same ensemble on every rank; run_sharded slices it
+    opts = prob['opts']
     D = prob['forcing'].shape[2]
-    eng = engine.get_engine(local_rank)
-    dev = [eng.to_device(prob[k]) for k in ('forcing', 'doy', 'member_params', 'reach_params')]
-    out = torch.empty((5, D, 1, E), dtype=torch.float64, device=eng.tdev)
+    S = prob['reach_params'].shape[1]
+    n_or = S if prob['out_reaches'] is None else len(prob['out_reaches'])
+    ncols = bin(opts.out_mask).count('1')
+    rows = opts.n_periods if opts.n_periods > 0 else D
 
-    def one_step():
-        o, status, stats = eng.run(dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], prob['opts'], out=out)
-        by_slot = ensemble.member_summaries(o)                    # [5, 1, E] per-slot totals
-        summ = torch.empty_like(by_slot)
-        summ[..., stats['member_of_slot'].long()] = by_slot       # -> member order
-        if world > 1:       # the one exchange step: per-member summaries to rank 0 (RCCL over xGMI)
-            total = ensemble.gather_to_root(summ if backend == 'nccl' else summ.cpu(), E * world)
-        else:
-            total = summ
-        return status, stats, total
+    eng = engine.get_engine(local_rank)
+    # inputs: marshalled into pinned host arrays, uploaded once (resident in HBM before the timed region)
+    pinned = {}
+    for k in ('forcing', 'doy', 'member_params', 'reach_params'):
+        pinned[k] = engine.pinned_empty(prob[k].shape, prob[k].dtype)
+        pinned[k][...] = prob[k]
+
+    def upload():
+        t = [torch.from_numpy(pinned[k]).to(eng.tdev, non_blocking=True) for k in ('forcing', 'doy', 'member_params', 'reach_params')]
+        torch.cuda.synchronize()
+        return t
+    upload()
+    t0 = time.perf_counter()
+    dev = upload()
+    h2d_s = time.perf_counter() - t0
+    pod = None if prob['period_of_day'] is None else eng.to_device(prob['period_of_day'])
+
+    out = torch.empty((ncols, rows, n_or, e_local), dtype=torch.float64, device=eng.tdev)
+    out_bytes = out.numel() * 8
+    host_out = None
+    stream_note = None
+    if not args.no_stream:
+        try:
+            host_out = engine.pinned_empty((ncols, rows, n_or, e_local), np.float64)
+        except engine.EngineError as ex:          # not enough lockable host memory on this node
+            stream_note = "pinned host buffer of %.1f GB not available (%s): table left in HBM" % (out_bytes / 1e9, ex)
+
+    def run_fn(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=None, out_reaches=None, host=None):
+        return eng.run(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=forcing_of_member,
+                       out_reaches=out_reaches, out=out, period_of_day=pod, host_out=host)
+
+    def one_step(host):
+        return ensemble.run_sharded(run_fn, dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], opts,
+                                    out_reaches=prob['out_reaches'], sharded_inputs=(args.scaling == 'weak'),
+                                    total_members=e_total if args.scaling == 'weak' else None, host=host)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps, host):
+        fence()
+        t_begin = time.perf_counter()
+        res_, st_ = None, []
+        for _ in range(n_steps):
+            res_ = one_step(host)
+            st_.append(res_['stats'])
+        fence()
+        dt = time.perf_counter() - t_begin
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.tdev if backend == 'nccl' else 'cpu')
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), res_, st_
+
     for _ in range(args.warmup):
-        one_step()
-    fence()
-    t0 = time.perf_counter()
-    kernel_ms, rhs = [], 0
-    for _ in range(args.steps):
-        status, stats, total = one_step()
-        kernel_ms.append(stats['kernel_ms'])
-        rhs = stats['rhs_evals']
-    fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev if backend == 'nccl' else 'cpu')
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        one_step(host_out)
+    elapsed, res, step_stats = timed(args.steps, host_out)
+    status, stats = res['status'], res['stats']
     n_bad = int((status != 0).sum().item())
 
+    # the device-resident rate beside it (same kernel, table left in HBM)
+    elapsed_dev = None
+    if host_out is not None:
+        one_step(None)
+        elapsed_dev, _, _ = timed(max(1, min(args.steps, 3)), None)
+        # leave a streamed run's table on both sides for the parity sample below
+        one_step(host_out)
+        torch.cuda.synchronize()
+
     if rank == 0:
-        cd_per_step = float(E) * world * D                         # S = 1 reach
-        ms_per_step = elapsed / args.steps * 1e3
-        value = cd_per_step / (elapsed / args.steps)
-        k_ms = float(np.mean(kernel_ms))
-        achieved = BYTES_PER_CD_REACH5 * float(E) * D / (k_ms * 1e-3) / 1e9      # GB/s, this rank's launch
-        traffic = None
+        cd_per_step = float(e_total) * S * D
+        sec_per_step = elapsed / args.steps
+        value = cd_per_step / sec_per_step
+        k_ms = float(np.mean([s['kernel_ms'] for s in step_stats]))
+        rhs = step_stats[-1]['rhs_evals']
+        cd_rank = float(e_local) * S * D
+        alg_bytes = cfg['bytes_per_cd'] * cd_rank
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9                  # GB/s, this rank's launch
+        khash = kernel_source_hash()
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            if tj.get('members') == E and tj.get('days') == D:
-                traffic = tj.get('hbm_bytes_per_launch')
-        rhs_per_cd = rhs / (float(E) * D)
+            ent = tj.get(args.config) or {}
+            if ent.get('members') == e_local and ent.get('days') == D and ent.get('kernel_source_hash') == khash:
+                traffic = ent.get('hbm_bytes_per_launch')
+            else:
+                traffic_note = "profiles/traffic.json does not describe this build/shape (kernel_source_hash %s): null" % khash
+        waves = (e_local + 63) // 64
         line = {
             "metric": "catchment-days/sec (ensemble x reaches x days)", "value": value, "unit": "catchment-days/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Tarland Monte-Carlo parameter ensemble (BASELINE config C3): 1 sub-catchment, "
-                                   "2 land-use soil boxes, 30-yr daily 1981-2010 (10957 d), %d members per GPU, "
-                                   "REACH-5 daily output, Cash-Karp 5(4) on the augmented system, rtol=1e-8" % E,
-                       "members_per_gpu": E, "reaches": 1, "days": D, "outputs": marshal.REACH5_COLUMNS,
-                       "solver": {k: getattr(prob['opts'], k) for k in ('integrator', 'rtol', 'atol', 'project_vr')},
-                       "parallelism": "ensemble shards, %d GPU(s), no data-path collective; final gather of "
-                                      "per-member summaries" % world},
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": cfg['dtype'], "data": "synthetic",
+            "config": {"workload": "%s; %d members %s; output: %s" % (cfg['what'], n_arg, "per GPU" if args.scaling == 'weak' else "in all, split over the GPUs", cfg['out']),
+                       "name": args.config, "members_per_gpu": e_local, "members_total": e_total, "reaches": S, "days": D,
+                       "outputs": marshal.columns_of_mask(opts.out_mask),
+                       "solver": {k: getattr(opts, k) for k in ('integrator', 'rtol', 'atol', 'project_vr')},
+                       "parity_grade": cfg['parity_grade'],
+                       "parallelism": "ensemble shards (ensemble.run_sharded), %d GPU(s), no data-path collective; final gather "
+                                      "of per-member summaries over %s" % (world, 'RCCL' if backend == 'nccl' else backend)},
+            "value_includes": ("output table delivered to pinned host memory (streamed per 256-day chunk beside the kernel) + "
+                               "per-member summaries gathered on rank 0; inputs resident in HBM") if host_out is not None
+                              else "output table left in HBM + per-member summaries gathered on rank 0; inputs resident in HBM",
+            "value_device_resident": None if elapsed_dev is None else cd_per_step / (elapsed_dev / max(1, min(args.steps, 3))),
+            "value_h2d_inclusive": cd_per_step / (sec_per_step + h2d_s),
+            "transfer": {"out_bytes_per_gpu": out_bytes, "h2d_input_ms": h2d_s * 1e3,
+                         "run_wall_ms": float(np.mean([s['wall_ms'] for s in step_stats])),
+                         "d2h_tail_ms": float(np.mean([s['d2h_tail_ms'] for s in step_stats])),
+                         "streamed_chunks": int(step_stats[-1]['streamed_chunks']),
+                         "d2h_gbs_over_run": None if host_out is None else out_bytes / (float(np.mean([s['wall_ms'] for s in step_stats])) * 1e-3) / 1e9,
+                         "pcie_spec_gbs": PCIE_SPEC_GBS, "note": stream_note},
+            "occupancy": {"waves_per_gpu": waves, "simd_slots": 1024, "rounds": waves / 1024.0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "simplyp_%s_kernel<%d, false>" % ("queue" if stats.get('queued') else "chain", prob['opts'].integrator),
-                         "kernel_ms": k_ms,
-                         "pilot_ms": stats.get('pilot_ms', 0.0),
-                         "algorithmic_bytes_per_launch": BYTES_PER_CD_REACH5 * float(E) * D,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": "simplyp_%s_kernel<%d, false>" % ("queue" if stats.get('queued') else "chain", opts.integrator),
+                         "kernel_ms": k_ms, "pilot_ms": stats.get('pilot_ms', 0.0),
+                         "bytes_per_catchment_day": cfg['bytes_per_cd'], "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the path is fp64-VALU-bound, not HBM-bound: see fp64_valu"},
-            "fp64_valu": {"rhs_evals_per_catchment_day": rhs_per_cd, "simt_efficiency": stats.get('simt_efficiency'),
+            "fp64_valu": {"rhs_evals_per_catchment_day": rhs / cd_rank, "simt_efficiency": stats.get('simt_efficiency'),
+                          "rejected_per_step": (step_stats[-1]['rejected'] / float(step_stats[-1]['steps'])) if step_stats[-1]['steps'] else None,
                           "flops_per_attempt": FLOPS_PER_ATTEMPT,
                           "achieved_tflops": FLOPS_PER_ATTEMPT * (rhs / 6.0) / (k_ms * 1e-3) / 1e12,
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                           "frac": FLOPS_PER_ATTEMPT * (rhs / 6.0) / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                          "note": "useful lane-attempts only (lanes idling in a diverged wave are not counted); peak = all-FMA issue"},
+                          "note": "useful lane-attempts only (lanes idling in a diverged wave are not counted); peak = all-FMA issue"
+                                  + ("; flop count is the fp64 kernel's, this config runs fp32 stages" if args.config == 'c5' else "")},
             "members_flagged": n_bad,
-            "parity": None if args.no_parity else parity_check(eng, prob['opts']),
         }
+        if not args.no_parity:
+            line["parity"] = parity(args, eng, prob, opts, out, host_out, stats, e_local)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(prob, D)
-        print(json.dumps(line))
+            line["cpu_baseline"] = cpu_baseline(prob, D, S)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def parity_check(eng, opts):
-    """Accuracy that goes with the throughput number: the Tarland 1981-2010 base member through the same
-    kernel and solver settings, against the reference's own equations integrated by odeint(rtol=atol=1e-12)
-    (tests/golden/tarland_1981_2010_dynamic.npz, recorded from the unmodified reference)."""
+def parity(args, eng, prob, opts, out, host_out, stats, e_local):
+    """Accuracy that goes with the throughput number, two ways: (golden) the Tarland base member through the same
+    kernel and solver settings against the reference's own equations integrated by odeint(rtol=atol=1e-12)
+    (tests/golden, recorded from the unmodified reference); (timed_run_sample) seeded members pulled out of the
+    BENCHMARKED table -- slot-ordered, written by the timed kernel, host copy included -- against the CPU oracle."""
+    import numpy as np
+    import torch
+    res = {}
+    if args.config in ('c2', 'c3'):
+        res["golden"] = parity_golden(eng, opts)
+    from oracle import oracle
+    rng = np.random.default_rng(12345)
+    n_s = min(8 if args.config != 'c4' else 4, e_local)
+    members = np.sort(rng.choice(e_local, n_s, replace=False))
+    mos = stats.get('member_of_slot')
+    if mos is None:
+        slot_of = np.arange(e_local)
+    else:
+        slot_of = np.empty(e_local, dtype=np.int64)
+        slot_of[mos.cpu().numpy().astype(np.int64)] = np.arange(e_local)
+    slots = torch.as_tensor(slot_of[members], device=out.device)
+    got = out.index_select(3, slots).cpu().numpy()                            # [ncols, rows, n_or, n_s]
+    # rank 0's block of the ensemble: with strong scaling prob holds every member and rank 0 owns the first ones
+    mp = np.ascontiguousarray(prob['member_params'][:, members])
+    rp = np.ascontiguousarray(prob['reach_params'][:, :, members])
+    o = type(opts)()
+    import ctypes
+    ctypes.memmove(ctypes.byref(o), ctypes.byref(opts), ctypes.sizeof(opts))
+    o.n_periods = 0
+    if o.integrator == 3 and not getattr(oracle, 'HAS_F32_MIRROR', False):
+        o.integrator = 2
+    t0 = time.perf_counter()
+    ref, ref_status, _ = oracle.run(prob['forcing'], prob['doy'], mp, rp, prob['up_ptr'], prob['up_idx'], o,
+                                    out_reaches=prob['out_reaches'], n_threads=min(n_s, os.cpu_count() or 1))
+    if opts.n_periods > 0:
+        pod = prob['period_of_day']
+        red = np.zeros((ref.shape[0], opts.n_periods) + ref.shape[2:])
+        np.add.at(red, (slice(None), pod), ref)
+        ref = red
+    denom = np.maximum(np.abs(ref), 1e-300)
+    rel = np.abs(got - ref) / denom
+    rel = np.where(got == ref, 0.0, rel)
+    bar = 10.0 * opts.rtol if cfg_parity_grade(args) else 5e-4
+    res["timed_run_sample"] = {
+        "members": [int(m) for m in members], "max_rel_err_vs_oracle": float(np.nanmax(rel)), "bar": bar,
+        "what": "%d seeded members of the benchmarked table (slot order resolved through member_of_slot), every requested "
+                "column and row, against the CPU oracle with the same solver settings%s; bar = %s" %
+                (n_s, "" if cfg_parity_grade(args) else " in fp64 (the fp32-stage mode is not parity-grade)",
+                 "10 x rtol" if cfg_parity_grade(args) else "5e-4"),
+        "oracle_seconds": time.perf_counter() - t0}
+    if host_out is not None:
+        res["timed_run_sample"]["host_table_equals_device_table"] = bool(
+            np.array_equal(host_out[:, :, :, slot_of[members]], got, equal_nan=True))
+        if args.config in ('c2', 'c3', 'c5'):          # whole-table check (a device-side compare of a re-uploaded host copy would need 2x HBM)
+            step = max(1, host_out.shape[1] // 64)
+            sub = torch.from_numpy(np.ascontiguousarray(host_out[:, ::step])).to(out.device)
+            res["timed_run_sample"]["host_rows_checked"] = int(sub.shape[1])
+            res["timed_run_sample"]["host_rows_equal"] = bool(torch.equal(sub, out[:, ::step]))
+    if args.config == 'c2':
+        res["replicas_bit_identical"] = bool((out == out[..., :1]).all().item())
+    return res
+
+
+def cfg_parity_grade(args):
+    return CONFIGS[args.config]['parity_grade']
+
+
+def parity_golden(eng, opts):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import helpers
@@ -180,21 +400,41 @@ def parity_check(eng, opts):
             "columns": "9 reach outputs x 10957 days", "against": "reference ode_f + driver, odeint rtol=atol=1e-12 (golden fixture)"}
 
 
-def cpu_baseline(prob, D):
-    """The CPU oracle (a C port of the reference's equations with the same Cash-Karp scheme; the Python
-    reference cannot travel to this box) timed on the host cores, on a bounded sample of the same workload."""
+def cpu_baseline(prob, D, S):
+    """The CPU oracle (a C port of the reference's equations with the same solver; the Python reference cannot travel
+    to this box) timed on the host cores, on a bounded sample of the same workload: all cores used (<= 16) and one core."""
+    import ctypes
     from oracle import oracle
+    opts = prob['opts']
+    o = type(opts)()
+    ctypes.memmove(ctypes.byref(o), ctypes.byref(opts), ctypes.sizeof(opts))
+    o.n_periods = 0
+    if o.integrator == 3:
+        o.integrator = 2                    # the oracle's fp32 mirror exists for parity, not speed: time the fp64 scheme at this tolerance
+
+    def leg(n, threads):
+        mp = prob['member_params'][:, :n].copy()
+        rp = prob['reach_params'][:, :, :n].copy()
+        t0 = time.perf_counter()
+        oracle.run(prob['forcing'], prob['doy'], mp, rp, prob['up_ptr'], prob['up_idx'], o,
+                   out_reaches=prob['out_reaches'], n_threads=threads)
+        return time.perf_counter() - t0
+
     cores = min(os.cpu_count() or 1, 16)
-    n = 32 * cores                                   # ~0.06 core-seconds per member-30-years -> ~30 core-seconds
-    mp = prob['member_params'][:, :n].copy()
-    rp = prob['reach_params'][:, :, :n].copy()
-    t0 = time.perf_counter()
-    out, status, stats = oracle.run(prob['forcing'], prob['doy'], mp, rp, prob['up_ptr'], prob['up_idx'],
-                                    prob['opts'], n_threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": n * D / dt, "unit": "catchment-days/s", "cores": cores, "kind": "port",
-            "sample": "first %d members of the same ensemble, all %d days, %d OpenMP threads, %.1f s wall"
-                      % (n, D, cores, dt)}
+    per_member = 0.06 * S * D / 10957.0                     # ~core-seconds per member (measured for the 30-year single reach)
+    n_all = max(cores, min(prob['member_params'].shape[1], int(30.0 / per_member)))
+    n_one = max(1, min(prob['member_params'].shape[1], int(6.0 / per_member)))
+    dt_all = leg(n_all, cores)
+    dt_one = leg(n_one, 1)
+    return {"value": n_all * S * D / dt_all, "unit": "catchment-days/s", "cores": cores, "kind": "port",
+            "sample": "first %d members of the same ensemble, all %d reaches and %d days, %d OpenMP threads, %.1f s wall"
+                      % (n_all, S, D, cores, dt_all),
+            "one_core": {"value": n_one * S * D / dt_one, "cores": 1,
+                         "sample": "first %d members, 1 thread, %.1f s wall" % (n_one, dt_one)},
+            "reference_python": {"value": [132, 180], "unit": "catchment-days/s per core", "kind": "reference",
+                                 "sample": "unmodified run_simply_p (odeint rtol=0.01), Tarland 1981-2010 / 2004, 1 core of the "
+                                           "survey container's Xeon 2.1 GHz -- BASELINE.md section 2; the Python reference "
+                                           "cannot travel to this node"}}
 
 
 if __name__ == '__main__':

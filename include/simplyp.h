@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 11
+#define SIMPLYP_ABI_VERSION 12
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -155,7 +155,11 @@ typedef struct {
     int32_t  n_launches;     /* kernel launches issued (one per routing stage)             */
     int32_t  balanced;       /* 1 when the cost-sorted member order was used                */
     int32_t  queued;         /* 1 when the time-chunk task queue kernel ran                  */
-    int32_t  reserved;
+    int32_t  streamed_chunks;/* simplyp_stream_out: time chunks whose device-to-host copy started while the kernel was still
+                                running (0 = the table was copied after the last launch)                           */
+    double   d2h_tail_ms;    /* simplyp_stream_out: device time between the end of the last launch and the last output
+                                byte reaching the host buffer (what the copy added to the run; 0 when not armed)   */
+    double   wall_ms;        /* host wall clock from the entry of simplyp_run / simplyp_run_async to the end of simplyp_sync */
 } simplyp_stats;
 
 typedef struct simplyp_ctx simplyp_ctx;
@@ -225,8 +229,10 @@ int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx,
                  int32_t* n_launches, int32_t* n_slots,
                  int32_t* launch_of_reach, int32_t* chain_of_reach, int32_t* pos_in_chain, int32_t* route_slot);
 
-/* Same as simplyp_run but only enqueues on the context's stream (for overlap with the
- * caller's own copies); simplyp_sync() waits and fills `stats`. */
+/* Same as simplyp_run but returns once the main launch is enqueued on the context's stream (for overlap with the
+ * caller's own copies); simplyp_sync() waits and fills `stats`.  With load balancing active (opts.balance) the call
+ * first BLOCKS for the pilot: pilot launches, a device-to-host copy of the cost table, the member ordering on host
+ * threads and the upload of the permutation (stats.pilot_ms, ~12 ms for 100 000 members) happen before it returns. */
 int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
                       const double* forcing, const int32_t* doy, const int32_t* period_of_day,
                       const int32_t* forcing_of_member,
@@ -235,6 +241,22 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
                       const int32_t* out_reaches, int32_t n_out_reaches,
                       double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals);
 int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats);
+
+/*
+ * simplyp_stream_out -- deliver the NEXT run's output table to host memory as well (one-shot; NULL disarms).
+ * The reference produces its 25 values per catchment-day in host memory (model.py:644, :721-724); an ensemble's table is
+ * tens of GB, so the copy is overlapped with the computation: adaptive integrators then run through the time-chunk task
+ * queue (opts.time_chunk_days = 0 behaves like 256), the wave that finishes the last task of a time chunk raises a flag in
+ * pinned host memory, and a host thread of the library enqueues that chunk's rows (one contiguous block per column) on a
+ * second HIP stream while later chunks compute.  simplyp_sync / simplyp_run return once the last byte is in `host_out`;
+ * stats.d2h_tail_ms is what the copy added after the last launch.  Runs without time chunks (RK4, opts.time_chunk_days < 0,
+ * time-reduced rows, D <= 256) copy the whole table after the last launch.
+ *   host_out    host  same layout and size as `out` (simplyp_out_bytes); pinned memory (simplyp_host_alloc) for the copy
+ *                     engine to run at PCIe speed beside the kernel -- pageable memory works, slowly
+ *   host_bytes  capacity of host_out, checked against the table size at the run
+ * The device table `out` is written as always (it feeds simplyp_gof / simplyp_waterbody).
+ */
+int simplyp_stream_out(simplyp_ctx* ctx, double* host_out, int64_t host_bytes);
 
 /* Host-pinned staging buffers for callers that do not use torch (hipHostMalloc/hipHostFree). */
 void* simplyp_host_alloc(int64_t bytes);

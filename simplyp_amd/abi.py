@@ -2,7 +2,7 @@
 
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1
@@ -32,7 +32,7 @@ class Opts(C.Structure):
 class Stats(C.Structure):
     _fields_ = [('rhs_evals', C.c_uint64), ('steps', C.c_uint64), ('rejected', C.c_uint64),
                 ('kernel_ms', C.c_double), ('pilot_ms', C.c_double), ('simt_efficiency', C.c_double), ('n_launches', C.c_int32), ('balanced', C.c_int32),
-                ('queued', C.c_int32), ('reserved', C.c_int32)]
+                ('queued', C.c_int32), ('streamed_chunks', C.c_int32), ('d2h_tail_ms', C.c_double), ('wall_ms', C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <thread>
 #include <cstdarg>
@@ -43,6 +44,27 @@ struct simplyp_ctx {
     DeviceBuf gof_lists;      // goodness-of-fit day lists, observations, shifts (simplyp_gof)
     DeviceBuf gof_partial;    // [n_chunks][R][78][E] partial sums
     DeviceBuf queue;          // ticket, error, done[n_groups] (uint32) | ckpt[CKPT_N][E] (double)
+    // streamed output (simplyp_stream_out): the armed destination, the chunk flags the queue kernel raises in pinned host
+    // memory, and the host thread that turns a raised flag into the D2H copies of that chunk's rows on `copy_stream`
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy_done = nullptr;
+    double* stream_host = nullptr;      // armed for the next run (one-shot)
+    int64_t stream_host_bytes = 0;
+    uint32_t* host_ready = nullptr;     // [host_ready_cap] hipHostMalloc
+    size_t host_ready_cap = 0;
+    DeviceBuf chunk_count;              // [n_chunks] uint32
+    struct CopyPlan {
+        const double* dev = nullptr;
+        double* host = nullptr;
+        int ncols = 0, n_chunks = 0, chunk_days = 0;
+        size_t D = 0, row_doubles = 0;  // rows per column, doubles per row (n_out_reaches * E)
+    } copy_plan;
+    std::thread copier;
+    std::atomic<int> run_over{0};       // set by simplyp_sync once the launches have finished (the copier stops waiting for flags)
+    int copy_error = 0;                 // first hipError_t the copier saw
+    int streamed_chunks = 0;            // chunks whose copy started before the kernel had finished
+    bool copy_pending = false;
+    std::chrono::steady_clock::time_point t_begin;
     int queued = 0;           // last run used the task-queue kernel
     int n_simd_slots = 1024;  // CUs x 4 SIMDs: wave slots at one resident wave per SIMD
     int balanced = 0;         // last run used the cost-sorted member order
@@ -313,6 +335,39 @@ void order_members(const std::vector<uint32_t>& cost, int n_win, int E, std::vec
     for (int e = 0; e < E; ++e) perm[e] = (int32_t)(uint32_t)key[e];
 }
 
+// Host side of the streamed output: wait for the kernel to raise a chunk's flag (or for the run to be over), then enqueue the
+// chunk's rows of every column on the copy stream.  Rows of one chunk are contiguous inside a column of `out`
+// ([col][day][reach][member]), so a chunk is `ncols` plain copies.
+void copier_main(simplyp_ctx* ctx)
+{
+    (void)hipSetDevice(ctx->device);
+    const simplyp_ctx::CopyPlan& p = ctx->copy_plan;
+    // No HIP call inside the wait: hipEventQuery on the run's stop event blocks for as long as another thread sits in
+    // hipEventSynchronize on it (measured: the first query returned when the kernel ended).  The flags live in host memory;
+    // "the run is over" comes from simplyp_sync (or the error paths) through `run_over`.
+    bool run_over = false;
+    const bool dbg = getenv("SIMPLYP_DEBUG") != nullptr;
+    for (int c = 0; c < p.n_chunks; ++c) {
+        while (!run_over && __atomic_load_n(&ctx->host_ready[c], __ATOMIC_ACQUIRE) == 0u) {
+            if (ctx->run_over.load(std::memory_order_acquire)) { run_over = true; break; }
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        if (!run_over) ++ctx->streamed_chunks;
+        if (dbg && (c < 3 || c + 2 > p.n_chunks))
+            fprintf(stderr, "[simplyp] copier: chunk %d ready=%u over=%d at %.1f ms\n", c, ctx->host_ready[c], (int)run_over,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count());
+        const size_t d0 = (size_t)c * p.chunk_days, nd = std::min<size_t>(p.chunk_days, p.D - d0);
+        for (int j = 0; j < p.ncols; ++j) {
+            const size_t off = ((size_t)j * p.D + d0) * p.row_doubles;
+            hipError_t err = hipMemcpyAsync(p.host + off, p.dev + off, nd * p.row_doubles * sizeof(double),
+                                            hipMemcpyDeviceToHost, ctx->copy_stream);
+            if (err != hipSuccess && !ctx->copy_error) ctx->copy_error = (int)err;
+        }
+    }
+    hipError_t err = hipEventRecord(ctx->ev_copy_done, ctx->copy_stream);
+    if (err != hipSuccess && !ctx->copy_error) ctx->copy_error = (int)err;
+}
+
 int check_args(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts, const void* forcing,
                const void* mp, const void* rp, const int32_t* up_ptr, const void* out, const void* status,
                const int32_t* out_reaches, int32_t n_out_reaches)
@@ -373,6 +428,8 @@ int simplyp_ctx_create(int device, simplyp_ctx** out)
     if (err == hipSuccess) { ctx->own_stream = true; err = hipEventCreate(&ctx->ev_start); }
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_main);
+    if (err == hipSuccess) err = hipEventCreate(&ctx->ev_copy_done);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (err == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -392,13 +449,15 @@ int simplyp_ctx_set_stream(simplyp_ctx* ctx, void* stream)
     if (!ctx) return SIMPLYP_ERR_ARG;
     if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is pending; call simplyp_sync first");
     (void)hipSetDevice(ctx->device);
-    if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr; ctx->own_stream = false; }
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-    } else {
+    if (!stream) {
+        // back to a private stream: the one the context already owns is kept (no create/destroy per call)
+        if (ctx->own_stream && ctx->stream) return SIMPLYP_OK;
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
+        return SIMPLYP_OK;
     }
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr; ctx->own_stream = false; }
+    ctx->stream = (hipStream_t)stream;
     return SIMPLYP_OK;
 }
 
@@ -407,6 +466,12 @@ void simplyp_ctx_destroy(simplyp_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->run_over.store(1, std::memory_order_release);
+    if (ctx->copier.joinable()) ctx->copier.join();
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->ev_copy_done) (void)hipEventDestroy(ctx->ev_copy_done);
+    if (ctx->host_ready) (void)hipHostFree(ctx->host_ready);
+    if (ctx->chunk_count.ptr) (void)hipFree(ctx->chunk_count.ptr);
     if (ctx->route.ptr) (void)hipFree(ctx->route.ptr);
     if (ctx->sched.ptr) (void)hipFree(ctx->sched.ptr);
     if (ctx->counters.ptr) (void)hipFree(ctx->counters.ptr);
@@ -475,7 +540,7 @@ int simplyp_plan(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_
     SIMPLYP_GUARD(nullptr, plan_impl(S, up_ptr, up_idx, n_launches, n_slots, launch_of_reach, chain_of_reach, pos_in_chain, route_slot))
 }
 
-static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
+static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
                           const double* forcing, const int32_t* doy, const int32_t* period_of_day,
                           const int32_t* forcing_of_member,
                           const double* member_params, const double* reach_params,
@@ -487,6 +552,15 @@ static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
                         out_reaches, n_out_reaches);
     if (rc != SIMPLYP_OK) return rc;
     if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is already pending on this context; call simplyp_sync");
+    ctx->t_begin = std::chrono::steady_clock::now();
+    // streamed output armed by simplyp_stream_out: one-shot
+    double* const host_out = ctx->stream_host;
+    const int64_t host_out_bytes = ctx->stream_host_bytes;
+    ctx->stream_host = nullptr; ctx->stream_host_bytes = 0;
+    ctx->copy_pending = false; ctx->copy_error = 0; ctx->streamed_chunks = 0;
+    if (host_out && host_out_bytes < simplyp_out_bytes(dims, opts, out_reaches ? n_out_reaches : dims->S))
+        return fail(ctx, SIMPLYP_ERR_ARG, "simplyp_stream_out: host buffer of %lld bytes is smaller than the output table (%lld)",
+                    (long long)host_out_bytes, (long long)simplyp_out_bytes(dims, opts, out_reaches ? n_out_reaches : dims->S));
     if (opts->dynamic_erod && !doy) return fail(ctx, SIMPLYP_ERR_ARG, "doy is required when dynamic_erod is set");
     if (opts->n_periods < 0 || (opts->n_periods > 0 && !period_of_day))
         return fail(ctx, SIMPLYP_ERR_ARG, "n_periods > 0 needs period_of_day (and n_periods must not be negative)");
@@ -614,8 +688,10 @@ static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     // the long waves first and back-fills with the short ones (longest-processing-time-first).
     int chunk_days = opts->time_chunk_days > 0 ? opts->time_chunk_days : 256;
     chunk_days = ((chunk_days + simplyp::TILE_D - 1) / simplyp::TILE_D) * simplyp::TILE_D;
+    // (a streamed output wants time chunks: their rows travel to the host while later chunks compute)
+    const bool stream_chunks = host_out && opts->n_periods == 0;
     bool want_queue = opts->integrator != SIMPLYP_INTEG_RK4 && D > chunk_days &&
-        (opts->time_chunk_days > 0 ||
+        (opts->time_chunk_days > 0 || (stream_chunks && opts->time_chunk_days == 0) ||
          (opts->time_chunk_days == 0 && ((S == 1 && (int)gx > ctx->n_simd_slots) || (S > 1 && (int)gx < ctx->n_simd_slots))));
     int pilot_days = opts->balance_pilot_days > 0 ? opts->balance_pilot_days : 64;
     if (pilot_days > D) pilot_days = D;
@@ -767,6 +843,25 @@ static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
             q.down_ptr = dq + off_dptr; q.down_idx = dq + off_didx;
             q.ckpt = (double*)(base + flags_bytes + ints_bytes);
             q.n_groups = G; q.n_pairs = (int)pair_idx.size(); q.chunk_days = chunk_days; q.ring_chunks = ring_chunks;
+            q.chunk_count = nullptr; q.host_ready = nullptr; q.tasks_per_chunk = (unsigned)S * (unsigned)G;
+            if (stream_chunks) {
+                rc = ensure(ctx, ctx->chunk_count, (size_t)n_chunks * sizeof(unsigned));
+                if (rc != SIMPLYP_OK) return rc;
+                if ((size_t)n_chunks > ctx->host_ready_cap) {
+                    if (ctx->host_ready) { (void)hipHostFree(ctx->host_ready); ctx->host_ready = nullptr; ctx->host_ready_cap = 0; }
+                    // COHERENT (fine-grained) host memory, asked for explicitly: a flag raised by a running kernel must reach the
+                    // polling host thread before the kernel ends, which only fine-grained memory promises
+                    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->host_ready, (size_t)n_chunks * sizeof(uint32_t),
+                                               hipHostMallocCoherent | hipHostMallocMapped));
+                    ctx->host_ready_cap = (size_t)n_chunks;
+                }
+                memset(ctx->host_ready, 0, (size_t)n_chunks * sizeof(uint32_t));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->chunk_count.ptr, 0, (size_t)n_chunks * sizeof(unsigned), ctx->stream));
+                q.chunk_count = (unsigned*)ctx->chunk_count.ptr;
+                q.host_ready = ctx->host_ready;
+                ctx->copy_plan.n_chunks = n_chunks;
+                ctx->copy_plan.chunk_days = chunk_days;
+            }
             q.max_polls = 20000000u;      // x (s_sleep 64 ~ 2 us): a wait longer than ~40 s means something is broken
             if (const char* mp_env = getenv("SIMPLYP_QUEUE_MAX_POLLS")) q.max_polls = (unsigned)strtoul(mp_env, nullptr, 10);
             simplyp::KernelArgs k = a;
@@ -805,8 +900,44 @@ static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
         ctx->n_launches = (int)sch.launches.size();
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    if (host_out) {
+        simplyp_ctx::CopyPlan& cp = ctx->copy_plan;
+        cp.dev = out; cp.host = host_out;
+        cp.ncols = popcount32(a.out_mask);
+        cp.D = (size_t)(opts->n_periods > 0 ? opts->n_periods : D);
+        cp.row_doubles = (size_t)n_out_reaches * E;
+        if (ctx->queued && stream_chunks) {
+            ctx->run_over.store(0, std::memory_order_release);
+            ctx->copier = std::thread(copier_main, ctx);       // chunk by chunk, beside the kernel
+        } else {
+            // no time chunks in this run (chain kernel, RK4, time-reduced rows): the whole table follows the last launch
+            HIP_TRY(ctx, hipMemcpyAsync(host_out, out, cp.ncols * cp.D * cp.row_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_copy_done, ctx->stream));
+        }
+        ctx->copy_pending = true;
+    }
     ctx->pending = true;
     return SIMPLYP_OK;
+}
+
+// Errors met after work has been enqueued must not leave it in flight behind the caller's back.
+static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
+                          const double* forcing, const int32_t* doy, const int32_t* period_of_day,
+                          const int32_t* forcing_of_member,
+                          const double* member_params, const double* reach_params,
+                          const int32_t* up_ptr, const int32_t* up_idx,
+                          const int32_t* out_reaches, int32_t n_out_reaches,
+                          double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals)
+{
+    const int rc = run_async_body(ctx, dims, opts, forcing, doy, period_of_day, forcing_of_member, member_params, reach_params,
+                                  up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status, member_of_slot, member_rhs_evals);
+    if (rc != SIMPLYP_OK && ctx && !ctx->pending) {
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        ctx->run_over.store(1, std::memory_order_release);
+        if (ctx->copier.joinable()) ctx->copier.join();
+        ctx->copy_pending = false;
+    }
+    return rc;
 }
 
 int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
@@ -832,6 +963,17 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] sync: stream idle\n");
+    float ms_tail = 0.f;
+    const bool copied = ctx->copy_pending;
+    if (ctx->copy_pending) {
+        ctx->copy_pending = false;
+        ctx->run_over.store(1, std::memory_order_release);     // the launches are done: whatever flag is still down stays down
+        if (ctx->copier.joinable()) ctx->copier.join();        // every chunk's copy is enqueued when it returns
+        if (ctx->copy_error)
+            return fail(ctx, SIMPLYP_ERR_DEVICE, "streamed output: a device-to-host copy failed: %s", hipGetErrorString((hipError_t)ctx->copy_error));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_copy_done));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms_tail, ctx->ev_stop, ctx->ev_copy_done));
+    }
     if (ctx->queued) {
         unsigned err = 0;
         HIP_TRY(ctx, hipMemcpy(&err, (unsigned*)ctx->queue.ptr + 1, sizeof(err), hipMemcpyDeviceToHost));
@@ -852,7 +994,20 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->n_launches = ctx->n_launches;
         stats->balanced = ctx->balanced;
         stats->queued = ctx->queued;
+        stats->streamed_chunks = copied ? ctx->streamed_chunks : 0;
+        stats->d2h_tail_ms = copied ? ms_tail : 0.0;
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();
     }
+    return SIMPLYP_OK;
+}
+
+int simplyp_stream_out(simplyp_ctx* ctx, double* host_out, int64_t host_bytes)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is pending on this context; call simplyp_sync first");
+    if (host_out && host_bytes <= 0) return fail(ctx, SIMPLYP_ERR_ARG, "simplyp_stream_out: host_bytes must be > 0");
+    ctx->stream_host = host_out;
+    ctx->stream_host_bytes = host_out ? host_bytes : 0;
     return SIMPLYP_OK;
 }
 

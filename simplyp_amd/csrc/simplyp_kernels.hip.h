@@ -1033,6 +1033,12 @@ struct QueueArgs {
     const int* down_idx;
     int n_groups, n_pairs, chunk_days, ring_chunks;
     unsigned max_polls;
+    // streamed output (simplyp_stream_out): tasks finished per time chunk; the wave whose task completes a chunk raises the
+    // chunk's flag in host-pinned memory, and a host thread then copies that chunk's rows of `out` to the host on a second
+    // stream while later chunks compute.  nullptr = off.
+    unsigned* chunk_count;     // [n_chunks] device
+    unsigned* host_ready;      // [n_chunks] host-pinned, device-visible
+    unsigned tasks_per_chunk;  // S * n_groups
 };
 
 // Wait until *flag >= need.  Executed by the whole wave on a wave-uniform address (the 64 identical loads are
@@ -1095,6 +1101,16 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_store(&q.done[(size_t)s * G + g], (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q.chunk_count) {
+                // every task adds to its chunk's counter AFTER its own release (above: the XCD's L2 has been written back and
+                // the wait has drained), so when the last add arrives all rows of the chunk are in memory, where the copy engine
+                // reads them; the flag itself goes to host memory with a system-scope release
+                unsigned old = 0;
+                if (lane == 0) old = atomicAdd(&q.chunk_count[c], 1u);
+                old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+                if (old + 1u == q.tasks_per_chunk && lane == 0)
+                    __hip_atomic_store(&q.host_ready[c], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             k = queue_take_ticket(q, lane);
         } else {
             if (lane == 0) __hip_atomic_store(q.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -25,7 +25,8 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 ABI_SYMBOLS = ['simplyp_abi_version', 'simplyp_device_count', 'simplyp_ctx_create', 'simplyp_ctx_destroy',
                'simplyp_last_error', 'simplyp_ctx_set_stream', 'simplyp_out_bytes', 'simplyp_run',
                'simplyp_run_async', 'simplyp_sync', 'simplyp_plan', 'simplyp_host_alloc', 'simplyp_host_free',
-               'simplyp_device_alloc', 'simplyp_device_free', 'simplyp_memcpy_h2d', 'simplyp_memcpy_d2h', 'simplyp_gof']
+               'simplyp_device_alloc', 'simplyp_device_free', 'simplyp_memcpy_h2d', 'simplyp_memcpy_d2h', 'simplyp_gof',
+               'simplyp_stream_out']
 
 _lib = None
 
@@ -37,7 +38,7 @@ class EngineError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, 'simplyp_hip.hip'), os.path.join(CSRC, 'simplyp_kernels.hip.h'),
-            os.path.join(INCLUDE, 'simplyp.h')]
+            os.path.join(CSRC, 'simplyp_gof.hip.h'), os.path.join(INCLUDE, 'simplyp.h')]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -88,6 +89,8 @@ def lib():
     L.simplyp_gof.restype = C.c_int
     L.simplyp_gof.argtypes = [vp, C.POINTER(abi.Dims), C.c_uint32, C.POINTER(C.c_int32), C.c_int32, dp, i32p, dp, dp,
                               C.POINTER(C.c_double), dp, C.POINTER(abi.GofInfo)]
+    L.simplyp_stream_out.restype = C.c_int
+    L.simplyp_stream_out.argtypes = [vp, vp, C.c_int64]
     L.simplyp_plan.restype = C.c_int
     L.simplyp_plan.argtypes = [C.c_int32] + [C.POINTER(C.c_int32)] * 8
     L.simplyp_host_alloc.restype = vp
@@ -127,6 +130,37 @@ def _i32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
 
 
+class _PinnedBlock(object):
+    """Owner of one simplyp_host_alloc block; freed when the last numpy view dies."""
+
+    def __init__(self, nbytes):
+        self.ptr = lib().simplyp_host_alloc(C.c_int64(max(int(nbytes), 1)))
+        if not self.ptr:
+            raise EngineError("simplyp_host_alloc(%d bytes) failed (pinned host memory)" % nbytes)
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().simplyp_host_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory (simplyp_host_alloc = hipHostMalloc): what the marshalling code fills and
+    what ``Engine.run(..., host_out=...)`` streams the output table into, so that both directions move at PCIe speed
+    and asynchronously.  Needs the library and a HIP device."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    blk = _PinnedBlock(n * dtype.itemsize)
+    buf = (C.c_char * max(blk.nbytes, 1)).from_address(blk.ptr)
+    buf._owner = blk                                 # keeps the block alive as long as any view of it
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
 class Engine(object):
     """One device context.  ``run`` takes device tensors (torch) and returns device tensors."""
 
@@ -157,6 +191,21 @@ class Engine(object):
         except Exception:
             pass
 
+    def _bind_stream(self):
+        """Order the library's launches after whatever the caller has enqueued on torch's current stream.  A real torch
+        stream is handed to the library and used as is.  Torch's DEFAULT stream has handle 0, which the library would read
+        as "use your private stream" -- a non-blocking stream that is not ordered with the default stream at all -- so in
+        that case the pending work (input casts, the caller's own kernels) is waited for here and the context keeps its one
+        private stream.  The run itself is synchronous, so consumers on any stream are safe afterwards."""
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.tdev)
+        handle = cur.cuda_stream if self._use_torch_stream else 0
+        if handle:
+            self._check(lib().simplyp_ctx_set_stream(self._h, C.c_void_p(handle)), 'simplyp_ctx_set_stream')
+        else:
+            cur.synchronize()
+            self._check(lib().simplyp_ctx_set_stream(self._h, None), 'simplyp_ctx_set_stream')
+
     def _check(self, rc, what):
         if rc != 0:
             raise EngineError("%s failed (%d): %s" % (what, rc, lib().simplyp_last_error(self._h).decode()))
@@ -175,7 +224,7 @@ class Engine(object):
         return t.to(self.tdev).contiguous()
 
     def run(self, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing_of_member=None,
-            out_reaches=None, out=None, member_rhs=None, member_of_slot=None, period_of_day=None):
+            out_reaches=None, out=None, member_rhs=None, member_of_slot=None, period_of_day=None, host_out=None):
         """Integrate every (member, reach) through all days on the device.
 
         forcing [n_sets,2,D] (rows P, PET; [n_sets,3,D] = Precipitation, PET, T_air with ``opts.snow``), doy [D], member_params [NP_M,E], reach_params [NP_R,S,E] may be numpy
@@ -185,7 +234,10 @@ class Engine(object):
         columns of ``out`` are lane slots; ``member_of_slot`` (int32 device tensor [E], allocated here when
         not given and returned in stats['member_of_slot']) maps them back to members.  With
         ``opts.n_periods`` > 0 and ``period_of_day`` [D] (int32), ``out`` has one row per period holding
-        the sum of the daily values of that period.
+        the sum of the daily values of that period.  ``host_out``: a C-contiguous float64 numpy array shaped like ``out``
+        (page-locked: ``engine.pinned_empty``) that receives the table too, streamed time chunk by time chunk while the
+        kernel runs (``simplyp_stream_out``); the call returns when its last byte has arrived
+        (stats: ``streamed_chunks``, ``d2h_tail_ms``, ``wall_ms``).
         """
         torch = self.torch
         L = lib()
@@ -218,17 +270,20 @@ class Engine(object):
         elif tuple(out.shape) != (ncols, rows, n_or, E) or out.dtype != torch.float64 or not out.is_contiguous():
             raise ValueError("out must be a contiguous float64 device tensor of shape %s" % ((ncols, rows, n_or, E),))
         assert out.numel() * 8 == L.simplyp_out_bytes(C.byref(dims), C.byref(opts), n_or)
+        if host_out is not None:
+            if (not isinstance(host_out, np.ndarray) or host_out.dtype != np.float64 or not host_out.flags['C_CONTIGUOUS']
+                    or host_out.shape != (ncols, rows, n_or, E)):
+                raise ValueError("host_out must be a C-contiguous float64 numpy array of shape %s" % ((ncols, rows, n_or, E),))
         status = torch.empty((E,), dtype=torch.int32, device=self.tdev)
         if opts.out_slot_order and member_of_slot is None:
             member_of_slot = torch.empty((E,), dtype=torch.int32, device=self.tdev)
         stats = abi.Stats()
         with torch.cuda.device(self.tdev):
-            if self._use_torch_stream:
-                self._check(L.simplyp_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                            'simplyp_ctx_set_stream')
-            else:
-                torch.cuda.current_stream().synchronize()
+            self._bind_stream()
             ip = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.POINTER(C.c_int32))
+            if host_out is not None:
+                self._check(L.simplyp_stream_out(self._h, C.c_void_p(host_out.ctypes.data), C.c_int64(host_out.nbytes)),
+                            'simplyp_stream_out')
             rc = L.simplyp_run(self._h, C.byref(dims), C.byref(opts), f.data_ptr(), dy.data_ptr(),
                                None if pod is None else pod.data_ptr(),
                                None if fom is None else fom.data_ptr(), mp.data_ptr(), rp.data_ptr(),
@@ -270,11 +325,7 @@ class Engine(object):
         info = abi.GofInfo()
         dims = abi.Dims(E, S, D, 1)
         with torch.cuda.device(self.tdev):
-            if self._use_torch_stream:
-                self._check(L.simplyp_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                            'simplyp_ctx_set_stream')
-            else:
-                torch.cuda.current_stream().synchronize()
+            self._bind_stream()
             rc = L.simplyp_gof(self._h, C.byref(dims), int(out_mask),
                                None if oreach is None else oreach.ctypes.data_as(C.POINTER(C.c_int32)), n_or,
                                out.data_ptr(), None if member_of_slot is None else member_of_slot.data_ptr(),

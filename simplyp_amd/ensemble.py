@@ -35,54 +35,101 @@ def member_summaries(out, step_axis=1):
     return out.sum(dim=step_axis)
 
 
-def gather_to_root(local, n_members, group=None, dst=0):
+def _group_is_nccl(group=None):
+    import torch.distributed as dist
+    try:
+        return 'nccl' in str(dist.get_backend(group))
+    except Exception:
+        return False
+
+
+def gather_to_root(local, n_members, group=None, dst=0, widths=None):
     """Gather per-member data (member axis last) from every rank to ``dst``.
 
-    ``local`` is this rank's block (torch tensor, any device the backend supports); blocks may be
-    ragged by one member, so they are padded to the widest block for the collective.  Returns the
-    assembled ``[..., n_members]`` tensor on ``dst`` and ``None`` elsewhere.  With world size 1 (or
-    torch.distributed not initialised) it returns ``local`` unchanged.
+    ``local`` is this rank's block (torch tensor); blocks may be ragged, so they are padded to the widest block for
+    the collective.  ``widths``: members per rank (default: the contiguous split of ``n_members`` by
+    ``shard_bounds``).  With an ``nccl`` group (RCCL over xGMI) the blocks travel device to device; with ``gloo`` they
+    are staged through host memory.  Returns the assembled ``[..., n_members]`` tensor on ``dst`` (on the device
+    ``local`` lives on) and ``None`` elsewhere.  With world size 1 (or torch.distributed not initialised) it returns
+    ``local`` unchanged.
     """
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    widths = [b - a for a, b in (shard_bounds(n_members, world, r) for r in range(world))]
+    if widths is None:
+        widths = [b - a for a, b in (shard_bounds(n_members, world, r) for r in range(world))]
+    if len(widths) != world or sum(widths) != n_members:
+        raise ValueError("widths %s do not add up to %d members over %d ranks" % (widths, n_members, world))
     wmax = max(widths)
     if local.shape[-1] != widths[rank]:
         raise ValueError("rank %d holds %d members, expected %d" % (rank, local.shape[-1], widths[rank]))
-    pad = torch.zeros(local.shape[:-1] + (wmax,), dtype=local.dtype, device=local.device)
-    pad[..., :widths[rank]] = local
+    home = local.device
+    wire = local if (_group_is_nccl(group) or home.type == 'cpu') else local.cpu()
+    pad = torch.zeros(wire.shape[:-1] + (wmax,), dtype=wire.dtype, device=wire.device)
+    pad[..., :widths[rank]] = wire
     pad = pad.contiguous()
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, gather_list=bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([b[..., :w] for b, w in zip(bufs, widths)], dim=-1)
+    return torch.cat([b[..., :w] for b, w in zip(bufs, widths)], dim=-1).to(home)
 
 
 def run_sharded(run_fn, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts,
-                forcing_of_member=None, out_reaches=None, group=None, gather=True):
+                forcing_of_member=None, out_reaches=None, group=None, gather=True, sharded_inputs=False,
+                total_members=None, **run_kwargs):
     """Run this rank's member block through ``run_fn`` (normally ``Engine.run``) and gather the
     per-member summaries on rank 0.
 
-    Returns ``dict(bounds, out, status, stats, summaries, all_status)``; the last two are the
-    gathered tensors on rank 0 (``None`` on other ranks or when ``gather`` is False).
+    Default: ``member_params`` / ``reach_params`` / ``forcing_of_member`` hold the WHOLE ensemble on every rank and
+    each rank takes its contiguous block (strong scaling: a fixed ensemble split over the GPUs).
+    ``sharded_inputs=True``: the arrays already are this rank's own block (weak scaling: every rank brings its own
+    members); the global ensemble is the concatenation of the blocks in rank order, ``total_members`` its size
+    (default: the sum over the ranks, found with one all_gather of the block sizes).
+    Extra keyword arguments (``out=``, ``host_out=``, ``member_of_slot=`` ...) go to ``run_fn``.
+
+    Returns ``dict(bounds, out, status, stats, summaries, all_status)``; ``summaries`` ([n_cols, n_reaches, E_total],
+    the day-sums of every requested column, in MEMBER order whatever the order of the columns of ``out``) and
+    ``all_status`` are the gathered tensors on rank 0 (``None`` on other ranks or when ``gather`` is False).
     """
+    import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     else:
         world, rank = 1, 0
-    E = member_params.shape[-1]
-    mp, rp, fom, bounds = shard_arrays(member_params, reach_params, forcing_of_member, world, rank)
-    mp = mp.contiguous() if hasattr(mp, 'contiguous') else np.ascontiguousarray(mp)
-    rp = rp.contiguous() if hasattr(rp, 'contiguous') else np.ascontiguousarray(rp)
+    widths = None
+    if sharded_inputs:
+        mp, rp, fom = member_params, reach_params, forcing_of_member
+        e_local = int(mp.shape[-1])
+        if world > 1:
+            sizes = [None] * world
+            dist.all_gather_object(sizes, e_local, group=group)
+            widths = [int(x) for x in sizes]
+        else:
+            widths = [e_local]
+        E = sum(widths)
+        if total_members is not None and int(total_members) != E:
+            raise ValueError("total_members=%d but the ranks hold %d members" % (total_members, E))
+        lo = sum(widths[:rank])
+        bounds = (lo, lo + e_local)
+    else:
+        E = member_params.shape[-1]
+        mp, rp, fom, bounds = shard_arrays(member_params, reach_params, forcing_of_member, world, rank)
+        mp = mp.contiguous() if hasattr(mp, 'contiguous') else np.ascontiguousarray(mp)
+        rp = rp.contiguous() if hasattr(rp, 'contiguous') else np.ascontiguousarray(rp)
     out, status, stats = run_fn(forcing, doy, mp, rp, up_ptr, up_idx, opts, forcing_of_member=fom,
-                                out_reaches=out_reaches)
+                                out_reaches=out_reaches, **run_kwargs)
     res = dict(bounds=bounds, out=out, status=status, stats=stats, summaries=None, all_status=None)
     if gather:
-        res['summaries'] = gather_to_root(member_summaries(out), E, group)
-        res['all_status'] = gather_to_root(status, E, group)
+        summ = member_summaries(out)
+        mos = stats.get('member_of_slot') if isinstance(stats, dict) else None
+        if mos is not None and getattr(opts, 'out_slot_order', 0):
+            by_member = torch.empty_like(summ)            # columns of `out` are lane slots: back to member order
+            by_member[..., mos.long()] = summ
+            summ = by_member
+        res['summaries'] = gather_to_root(summ, E, group, widths=widths)
+        res['all_status'] = gather_to_root(status, E, group, widths=widths)
     return res

@@ -1,0 +1,218 @@
+"""Streamed output (simplyp_stream_out) and the BASELINE configurations at their stated sizes.
+
+The reference produces its 25 values per catchment-day in host memory (model.py:644, :721-724); the engine delivers an
+ensemble's table there chunk by chunk while later chunks compute.  Whatever the path (time-chunk task queue with the
+copy beside the kernel; chain kernel / RK4 / time-reduced rows with the copy behind the last launch), the host table
+must equal the device table bit for bit, and the device table must be what a run without streaming writes.
+"""
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+from simplyp_amd import abi, engine, marshal, synthetic
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REACH_COLS = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day',
+              'PPr_EndOfDay', 'PP_kg/day']
+
+
+def run(eng, m, **kw):
+    return eng.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'], **kw)
+
+
+def perturbed(name, E, seed=3, **kw):
+    m = helpers.marshal_scenario(name, E=E, **kw)
+    rng = np.random.default_rng(seed)
+    m['member_params'][marshal.PM_NAMES.index('fc')] *= rng.uniform(0.85, 1.15, E)
+    m['member_params'][marshal.PM_NAMES.index('T_g')] *= rng.uniform(0.6, 1.5, E)
+    m['member_params'][marshal.PM_NAMES.index('a_Q')] *= rng.uniform(0.6, 1.6, E)
+    return m
+
+
+@pytest.mark.parametrize('name,E,solver,expect_queue', [
+    ('tarland_1981_2010_dynamic', 700, None, True),                             # 43 chunks x 11 groups, copies beside the kernel
+    ('tarland_1981_2010_dynamic', 130, dict(time_chunk_days=512), True),        # longer chunks
+    ('tarland_2004_dynamic', 200, None, True),                                  # 366 days: 2 chunks, the second one ragged
+    ('tarland_2004_dynamic', 200, dict(time_chunk_days=-1), False),             # chain kernel: whole table after the launch
+    ('tarland_2004_dynamic', 70, dict(integrator='rk4', substeps=16), False),   # RK4 never runs through the queue
+    ('chain4_val_2004', 150, None, True),                                       # reach network, pipelined queue, 4 reaches out
+    ('confluence3_nc_2004', 96, dict(balance=1), True),                         # cost-ordered slots, member-order table
+])
+def test_host_table_equals_device_table(engine0, name, E, solver, expect_queue):
+    m = perturbed(name, E, out_mask=marshal.MASK_REACH5, solver=solver)
+    ref, ref_status, _ = run(engine0, m)                                        # no streaming
+    host = engine.pinned_empty(tuple(ref.shape))
+    host[...] = -7.0
+    out, status, st = run(engine0, m, host_out=host)
+    assert st['queued'] == (1 if expect_queue else 0)
+    assert np.array_equal(host, out.cpu().numpy(), equal_nan=True)
+    import torch
+    assert bool(torch.equal(out, ref)) and bool(torch.equal(status, ref_status))       # streaming does not change results
+    if expect_queue:
+        n_chunks = -(-m['forcing'].shape[2] // max(256, (solver or {}).get('time_chunk_days', 256)))
+        assert 0 <= st['streamed_chunks'] <= n_chunks
+    else:
+        assert st['streamed_chunks'] == 0
+    assert st['wall_ms'] > 0 and st['d2h_tail_ms'] >= 0
+    # the arm is one-shot: the next run leaves the host buffer alone
+    host[...] = -7.0
+    run(engine0, m)
+    assert float(host.max()) == -7.0 and float(host.min()) == -7.0
+
+
+def test_copies_overlap_the_kernel_on_a_long_run(engine0):
+    """30 years x 4096 members: all but the last few of the 43 chunks must have gone out while the kernel was still
+    running, and what the copy adds after the last launch is a small part of the run."""
+    m = perturbed('tarland_1981_2010_dynamic', 4096, out_mask=marshal.MASK_REACH5)
+    shape = (5, m['forcing'].shape[2], 1, 4096)
+    host = engine.pinned_empty(shape)
+    run(engine0, m, host_out=host)                                              # warm-up (allocations)
+    out, status, st = run(engine0, m, host_out=host)
+    assert st['queued'] == 1 and st['streamed_chunks'] >= 38, st
+    assert st['d2h_tail_ms'] < 0.25 * st['kernel_ms'], st
+    assert np.array_equal(host, out.cpu().numpy(), equal_nan=True)
+
+
+def test_time_reduced_rows_and_slot_order_are_streamed_too(engine0):
+    m = perturbed('tarland_1981_2010_dynamic', 300, out_mask=marshal.mask_of_columns(['Qr', 'TDP_kg/day']),
+                  solver=dict(out_slot_order=1, balance=1))
+    periods, pod = np.unique(m['met'].index.year.values, return_inverse=True)
+    m['opts'].n_periods = len(periods)
+    host = engine.pinned_empty((2, len(periods), 1, 300))
+    out, status, st = run(engine0, m, period_of_day=np.ascontiguousarray(pod, dtype=np.int32), host_out=host)
+    assert st['streamed_chunks'] == 0                      # sums are complete only when the run is
+    assert np.array_equal(host, out.cpu().numpy())
+    assert sorted(st['member_of_slot'].cpu().numpy().tolist()) == list(range(300))
+
+
+def test_pageable_host_buffer_and_argument_errors(engine0):
+    m = perturbed('tarland_2004_dynamic', 64, out_mask=marshal.MASK_REACH5)
+    host = np.full((5, 366, 1, 64), -1.0)                  # not pinned: slower, still correct
+    out, _, _ = run(engine0, m, host_out=host)
+    assert np.array_equal(host, out.cpu().numpy())
+    with pytest.raises(ValueError):
+        run(engine0, m, host_out=np.zeros((5, 366, 1, 63)))
+    with pytest.raises(ValueError):
+        run(engine0, m, host_out=np.zeros((5, 366, 1, 64), dtype=np.float32))
+    # straight through the C ABI: a host buffer smaller than the table is refused at the run, and the arm is spent
+    L = engine.lib()
+    small = engine.pinned_empty((100,))
+    assert L.simplyp_stream_out(engine0._h, C.c_void_p(small.ctypes.data), C.c_int64(small.nbytes)) == 0
+    with pytest.raises(engine.EngineError, match='smaller than the output table'):
+        run(engine0, m)
+    out2, _, _ = run(engine0, m)
+    import torch
+    assert bool(torch.equal(out, out2))
+
+
+def test_inputs_still_in_flight_on_torchs_default_stream(engine0):
+    """torch's default stream has handle 0, which the library reads as "private stream"; a cast launched on
+    the default stream just before the run must be finished before the kernels read its result."""
+    import torch
+    m = perturbed('tarland_2004_dynamic', 4096, out_mask=marshal.MASK_REACH5)
+    want, _, _ = run(engine0, m)
+    big = torch.from_numpy(m['member_params']).to('cuda')
+    for _ in range(3):
+        # a long-running producer on the default stream: the parameters are the LAST thing it writes
+        junk = torch.randn(8192, 8192, device='cuda')
+        junk = junk @ junk
+        mp_dev = (big.to(torch.float32).to(torch.float64) * 0 + big) + 0 * junk[0, 0].double()
+        got, _, _ = engine0.run(m['forcing'], m['doy'], mp_dev, m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])
+        assert bool(torch.equal(got, want))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                             # a real (non-default) torch stream is used as is
+        junk = torch.randn(8192, 8192, device='cuda')
+        junk = junk @ junk
+        mp_dev = big + 0 * junk[0, 0].double()
+        got, _, _ = engine0.run(m['forcing'], m['doy'], mp_dev, m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])
+    s.synchronize()
+    assert bool(torch.equal(got, want))
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configurations at their stated sizes
+
+def test_config_c2_exactly(engine0):
+    """C2 as SURVEY.md section 8(d) states it: Tarland 1981-2010 (10 957 days), 1024 identical copies of the base
+    parameters, all 25 columns (2.24 GB), delivered to host memory: every member equals the E = 1 run bit for bit,
+    and the base member meets the <= 1e-6 bar on the 9 reach outputs against the reference's odeint(rtol=atol=1e-12)
+    tables (tests/golden/tarland_1981_2010_dynamic.npz)."""
+    import torch
+    name = 'tarland_1981_2010_dynamic'
+    m = helpers.marshal_scenario(name, E=1024)
+    D = m['forcing'].shape[2]
+    assert D == 10957 and bin(m['opts'].out_mask).count('1') == 25
+    host = engine.pinned_empty((25, D, 1, 1024))
+    out, status, st = run(engine0, m, host_out=host)
+    assert int(status.max()) == 0 and out.numel() * 8 == 25 * 10957 * 1024 * 8
+    one = helpers.marshal_scenario(name, E=1)
+    o1, _, _ = run(engine0, one)
+    assert bool(torch.equal(out, o1.expand(-1, -1, -1, 1024)))
+    assert np.array_equal(host, out.cpu().numpy(), equal_nan=True)
+    gold = helpers.golden_tables(name, 'tight')['R'][1]
+    got = o1[..., 0, 0].cpu().numpy()
+    for c in REACH_COLS:
+        rel = np.abs(got[marshal.OUT_COLUMNS.index(c)] - gold[c].values) / np.abs(gold[c].values)
+        assert rel.max() < 1e-6, (c, rel.max())
+
+
+def test_config_c3_at_100k_members_through_the_benched_path(engine0, oracle_lib):
+    """C3 at its stated size: 100 000 Monte-Carlo members x 10 957 days, REACH-5, slot-order table, auto load balance +
+    task queue (the configuration bench.py times), table streamed to the host.  No member flagged; every member in
+    exactly one slot; seeded members pulled from the big table agree with the CPU oracle to 10 x rtol; a 4096-member
+    slice run on its own (chain kernel, no balancing) equals the big run bit for bit; host table == device table on a
+    row sample."""
+    import torch
+    E = 100000
+    pr = synthetic.c3_problem(E, solver=dict(out_slot_order=1))
+    D = pr['forcing'].shape[2]
+    host = engine.pinned_empty((5, D, 1, E))
+    out, status, st = run(engine0, pr, host_out=host)
+    assert st['queued'] == 1 and st['balanced'] == 1 and st['streamed_chunks'] >= 30, st
+    assert int((status != 0).sum()) == 0 and bool(torch.isfinite(out).all())
+    mos = st['member_of_slot']
+    assert int(torch.unique(mos).numel()) == E
+    slot_of = torch.empty(E, dtype=torch.long, device=out.device)
+    slot_of[mos.long()] = torch.arange(E, device=out.device)
+    rng = np.random.default_rng(2024)
+    pick = np.sort(rng.choice(E, 8, replace=False))
+    sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
+    ref, _, _ = oracle_lib.run(sub['forcing'], sub['doy'], sub['member_params'], sub['reach_params'], sub['up_ptr'],
+                               sub['up_idx'], sub['opts'], n_threads=8)
+    got = out[..., slot_of[torch.as_tensor(pick, device=out.device)]].cpu().numpy()
+    assert helpers.max_rel_err(got, ref, floor=1e-12) < 1e-7
+    sl = np.arange(4096) * 24
+    alone = dict(pr, member_params=pr['member_params'][:, sl], reach_params=pr['reach_params'][:, :, sl])
+    alone['opts'] = abi.make_opts(dynamic_epc0=True, out_mask=marshal.MASK_REACH5)
+    a = run(engine0, alone)[0]
+    assert bool(torch.equal(a, out[..., slot_of[torch.as_tensor(sl, device=out.device)]]))
+    rows = np.arange(0, D, 97)
+    assert bool(torch.equal(torch.from_numpy(np.ascontiguousarray(host[:, rows])).to(out.device), out[:, rows]))
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell: the parent must spawn its ranks before touching the GPU (gloo
+    rehearsal: two ranks share this box's one GPU) and relay rank 0's JSON line; weak and strong scaling."""
+    import json
+    env = dict(os.environ, SIMPLYP_BENCH_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    for scaling, per_gpu, total in (('weak', 1500, 3000), ('strong', 1500, 3000)):
+        members = per_gpu if scaling == 'weak' else total
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                            '--members', str(members), '--scaling', scaling, '--no-cpu-baseline'],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        assert j['n_gpus'] == 2 and j['scaling'] == scaling
+        assert j['config']['members_total'] == total and j['config']['members_per_gpu'] == per_gpu
+        assert j['value'] > 0 and j['parity']['timed_run_sample']['max_rel_err_vs_oracle'] < 1e-7
+        assert j['parity']['timed_run_sample']['host_table_equals_device_table'] is True
