@@ -99,7 +99,7 @@ def kernel_source_hash():
     measured on."""
     h = hashlib.sha256()
     for rel in ('simplyp_amd/csrc/simplyp_kernels.hip.h', 'simplyp_amd/csrc/simplyp_hip.hip',
-                'simplyp_amd/csrc/simplyp_gof.hip.h', 'include/simplyp.h'):
+                'simplyp_amd/csrc/simplyp_gof.hip.h', 'simplyp_amd/csrc/simplyp_waterbody.hip.h', 'include/simplyp.h'):
         with open(os.path.join(ROOT, rel), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -356,13 +356,13 @@ def parity(args, eng, prob, opts, out, host_out, stats, e_local):
     denom = np.maximum(np.abs(ref), 1e-300)
     rel = np.abs(got - ref) / denom
     rel = np.where(got == ref, 0.0, rel)
-    bar = 10.0 * opts.rtol if cfg_parity_grade(args) else 5e-4
+    bar = 10.0 * opts.rtol
     res["timed_run_sample"] = {
         "members": [int(m) for m in members], "max_rel_err_vs_oracle": float(np.nanmax(rel)), "bar": bar,
         "what": "%d seeded members of the benchmarked table (slot order resolved through member_of_slot), every requested "
-                "column and row, against the CPU oracle with the same solver settings%s; bar = %s" %
-                (n_s, "" if cfg_parity_grade(args) else " in fp64 (the fp32-stage mode is not parity-grade)",
-                 "10 x rtol" if cfg_parity_grade(args) else "5e-4"),
+                "column and row, against the CPU oracle with the same solver settings%s; bar = 10 x rtol" %
+                (n_s, "" if cfg_parity_grade(args) else " (its same-arithmetic mirror of the fp32-stage mode, which is not "
+                                                         "parity-grade: no <= 1e-6 claim against the reference)"),
         "oracle_seconds": time.perf_counter() - t0}
     if host_out is not None:
         res["timed_run_sample"]["host_table_equals_device_table"] = bool(

@@ -322,6 +322,61 @@ int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
                 const double* f_tdp, const double* reach_params,
                 const double* obs, double* gof, simplyp_gof_info* info);
 
+/* ---- receiving waterbody: the reference's sum_to_waterbody (model.py:851-900) for a whole ensemble -------------------- */
+enum {  /* columns of the reference's df_summed, in its order: the four summed series (vars_to_sum, :866), the three
+           volume-weighted concentrations (:886-888), derived_P_species (:842-845) */
+    SIMPLYP_WB_Q_CUMECS = 0, SIMPLYP_WB_MSUS_FLUX, SIMPLYP_WB_TDP_FLUX, SIMPLYP_WB_PP_FLUX,
+    SIMPLYP_WB_SS_MGL, SIMPLYP_WB_TDP_MGL, SIMPLYP_WB_PP_MGL,
+    SIMPLYP_WB_TP_MGL, SIMPLYP_WB_TP_FLUX, SIMPLYP_WB_SRP_MGL, SIMPLYP_WB_SRP_FLUX,
+    SIMPLYP_N_WB
+};
+#define SIMPLYP_WB_MASK_ALL ((uint32_t)((1u << SIMPLYP_N_WB) - 1u))
+
+typedef struct {
+    double  kernel_ms;        /* HIP events on the context's stream                                              */
+    int64_t bytes_moved;      /* algorithmic bytes: 32 read per member, day and summed reach + 8 written per member, day
+                                 and requested column                                                            */
+} simplyp_wb_info;
+
+/*
+ * simplyp_waterbody -- sum the daily series of the reaches that flow into the receiving waterbody
+ * (p_struc['In_final_flux?'] == 1, model.py:867) into one series per member, from the table a previous simplyp_run left
+ * on the device: Q_cumecs (= Qr * A_catch * 1000 / 86400 per reach, :784) and the three daily fluxes added in ascending
+ * reach order (DataFrame.sum: NaN counts as 0), concentrations = (flux / Q_cumecs) * 1000/86400, TP and SRP as
+ * derived_P_species.  Same operations in the same order as the reference: bit-identical to its restatement in
+ * oracle/waterbody.py.  The reference returns nothing for fewer than two flagged reaches (:872, :895); the host wrapper
+ * keeps that rule, this entry sums whatever it is given (n_sum >= 1).
+ *
+ *   dims, out_mask, out_reaches, n_out_reaches, out, member_of_slot   as for simplyp_gof (daily rows; the mask must
+ *                   contain Qr and the three fluxes)
+ *   f_tdp           device  [E], member order (p['f_TDP'])
+ *   reach_params    device  as in the run (row SIMPLYP_PR_A_CATCH is read)
+ *   sum_reaches     host    [n_sum] zero-based reach ids, ascending, each one of the table's output reaches; n_sum <= 16
+ *   wb_mask         bit c set -> column c (SIMPLYP_WB_*) is written
+ *   wb              device  [popcount(wb_mask)][D][E]; member axis in the order of `out`'s (slots when the run wrote
+ *                           slot order)
+ *   info            host    may be NULL
+ * Synchronous.
+ */
+int simplyp_waterbody(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                      const int32_t* out_reaches, int32_t n_out_reaches,
+                      const double* out, const int32_t* member_of_slot,
+                      const double* f_tdp, const double* reach_params,
+                      const int32_t* sum_reaches, int32_t n_sum,
+                      uint32_t wb_mask, double* wb, simplyp_wb_info* info);
+
+/*
+ * simplyp_gof_waterbody -- simplyp_gof for the summed series: statistics of every member's waterbody series (table
+ * written by simplyp_waterbody) against observations taken at the waterbody's inflow.
+ *   dims            E, D (S, n_forcing_sets ignored)
+ *   wb_mask, wb     as written by simplyp_waterbody; the mask must contain Q_cumecs and the three summed fluxes
+ *   obs             HOST  [SIMPLYP_N_GOF_VARS][D], NaN = no observation
+ *   gof             device [SIMPLYP_N_GOF_STATS][SIMPLYP_N_GOF_VARS][1][E], member order
+ */
+int simplyp_gof_waterbody(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t wb_mask, const double* wb,
+                          const int32_t* member_of_slot, const double* f_tdp,
+                          const double* obs, double* gof, simplyp_gof_info* info);
+
 #ifdef __cplusplus
 }
 #endif

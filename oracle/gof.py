@@ -53,7 +53,8 @@ def stats_of_pair(obs, sim):
     with np.errstate(divide='ignore', invalid='ignore'):
         lo, ls = np.log(o), np.log(s)
         row[1] = 1 - np.sum((o - s) ** 2) / np.sum((o - np.mean(o)) ** 2)
-        row[2] = 1 - np.sum((lo - ls) ** 2) / np.sum((lo - np.mean(lo)) ** 2)
+        # np.sum / np.mean of a pandas Series skip NaN (:442-443): a day with log(sim < 0) = NaN drops out of the sums
+        row[2] = 1 - np.nansum((lo - ls) ** 2) / np.nansum((lo - np.nanmean(lo)) ** 2)
         do, ds = o - np.mean(o), s - np.mean(s)
         row[3] = np.sum(do * ds) ** 2 / (np.sum(do * do) * np.sum(ds * ds))
         row[4] = 100 * np.sum(s - o) / np.sum(o)

@@ -13,6 +13,7 @@ from simplyp_amd import abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libsimplyp_oracle.so')
 _lib = None
+HAS_F32_MIRROR = True      # integrator 3 (fp32 stages) has a same-arithmetic mirror: cashkarp_aug_f32_day
 
 
 def build(force=False):

@@ -374,6 +374,190 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
 }
 
 /* ------------------------------------------------------------------------------------- */
+/*
+ * SIMPLYP_INTEG_CASHKARP_AUG_F32 -- the same-arithmetic mirror of the kernel's reduced-precision mode (BASELINE config
+ * C5: "fp32 state + fp64 mass-balance accumulators"; SysAugF / DayConstF / ck_day<SysAugF> in
+ * simplyp_amd/csrc/simplyp_kernels.hip.h).  NOT a parity-grade mode: fp32 stages cannot resolve rtol below ~3e-6; this
+ * mirror exists so that the fp32 kernel has a checker that does the same thing, not one that is merely close.
+ *   - the 11 Runge-Kutta states, every stage, the error norm and the step-size control are `float`;
+ *   - the day constants are formed in double exactly as the kernel hoists them (DayConst) and rounded to float once per day;
+ *   - the auxiliary states start each day from double-precision exp / pow rounded to float, and are re-evaluated in float
+ *     after every 8th attempt;
+ *   - the four daily integrals are accumulated in double from float increments; the state carried to the next day, Vr on
+ *     its invariant, the soil-P update and everything else outside the day's integration stay double.
+ * Remaining differences to the kernel: libm logf/expf/powf against v_log_f32 / v_exp_f32 (1-2 ulp of float), a true float
+ * division against v_rcp_f32 (+ one Newton step), and 0.9 err^-0.2 through powf -- all far below the step controller's
+ * own tolerance; an accept/reject decision may flip on them, after which the two runs are two valid integrations at the
+ * same rtol.  Tests compare at 10 x rtol.
+ */
+typedef struct {
+    float c0, aE, mu, fc, inv_d, invTsA, invTsS, invTg, Qgmin, inv_dg, beta, fA, fS, qin, omb, cQ, bQ, kM,
+          Esum, MsusUS, tA, tS, tg, tconst, cPP, PPrUS, invKv;
+} dayconst_f;
+
+static float gate_f(float u, float inv_d)            /* f_x as one clamped cubic, like the kernel's gate() */
+{
+    float s = u * inv_d;
+    s = fminf(fmaxf(s, 0.0f), 1.0f);
+    return s * s * fmaf(-2.0f, s, 3.0f);
+}
+
+static void dayconst_from_params(const ode_params* p, dayconst_f* c)
+{
+    const double omb = 1.0 - p->beta;
+    const double wA = p->f_A * (1 - p->f_NC_A);                       /* TDP source weights (:155-161) */
+    const double wNC = p->f_A * p->f_NC_A + p->f_S * p->f_NC_S;
+    const double tNC = omb * wNC * p->conc_TDPs_NC;
+    const double Kv = p->L_reach / (p->a_Q * 8.64 * 10000);
+    const double pA = (p->PlabA_i + p->P_inactive) / p->Msoil, pN = (p->PlabNC_i + p->P_inactive) / p->Msoil;
+    const double p0 = p->P_inactive / p->Msoil;
+    const double inv_dg = (p->Qg_min * 0.01 > 0.0) ? 1.0 / (p->Qg_min * 0.01) : 1.0e300;
+    c->c0 = (float)(p->P * (1 - p->f_quick));
+    c->aE = (float)(p->alpha * p->E);
+    c->mu = (float)p->mu; c->fc = (float)p->fc; c->inv_d = (float)(1.0 / (0.01 * p->fc));
+    c->invTsA = (float)(1.0 / p->T_s_A); c->invTsS = (float)(1.0 / p->T_s_S);
+    c->invTg = (float)(1.0 / p->T_g); c->Qgmin = (float)p->Qg_min;
+    c->inv_dg = (float)fmin(inv_dg, 1.0e30);
+    c->beta = (float)p->beta; c->fA = (float)p->f_A; c->fS = (float)p->f_S;
+    c->qin = (float)(p->Qq_i + p->Qr_US_i);
+    c->omb = (float)omb;
+    c->cQ = (float)(p->a_Q * (8.64 * 10000) / ((1 - p->b_Q) * p->L_reach));
+    c->bQ = (float)p->b_Q; c->kM = (float)p->k_M;
+    c->Esum = (float)(p->f_Ar * p->Esus_A + p->f_IG * p->Esus_IG + p->f_S * p->Esus_S);
+    c->MsusUS = (float)p->Msus_US_i;
+    c->tA = (float)(omb * wA * p->conc_TDPs_A + (p->NC_type == 1 ? tNC : 0.0));
+    c->tS = (float)(p->NC_type == 1 ? 0.0 : tNC);
+    c->tg = (float)(p->TDPg * p->A_catch);
+    c->tconst = (float)(p->Qq_i * (wA * p->conc_TDPs_A + wNC * p->conc_TDPs_NC) + p->TDPeff + p->TDPr_US_i);
+    c->cPP = (float)(p->E_PP * (p->f_Ar * p->Esus_A * ((1 - p->f_NC_Ar) * pA + p->f_NC_Ar * pN)
+                                + p->f_IG * p->Esus_IG * ((1 - p->f_NC_IG) * pA + p->f_NC_IG * pN)
+                                + p->f_S * p->Esus_S * ((1 - p->f_NC_S) * p0 + p->f_NC_S * pN)));
+    c->PPrUS = (float)p->PPr_US_i;
+    c->invKv = (float)(1.0 / Kv);
+}
+
+/* SysAugF::f, operation for operation.  z[11] = VsA VsS Vg Qr Msus TDPr PPr EA ES pb pk; q[4] = integrands of the
+ * daily integrals. */
+static void ode_aug_f32(const float* z, const dayconst_f* c, float* dz, float* q)
+{
+    const float uA = z[0] - c->fc, uS = z[1] - c->fc;
+    const float QsA = uA * gate_f(uA, c->inv_d) * c->invTsA;
+    const float QsS = uS * gate_f(uS, c->inv_d) * c->invTsS;
+    dz[0] = fmaf(c->aE, z[7] - 1.0f, c->c0) - QsA;
+    dz[1] = fmaf(c->aE, z[8] - 1.0f, c->c0) - QsS;
+    const float Qsum = fmaf(c->fA, QsA, c->fS * QsS);
+    const float ug = fmaf(z[2], c->invTg, -c->Qgmin);
+    const float Qg = fmaf(gate_f(ug, c->inv_dg), ug, c->Qgmin);
+    dz[2] = fmaf(c->beta, Qsum, -Qg);
+    const float Qr = z[3], pb = z[9], pk = z[10];
+    const float inflow = fmaf(c->omb, Qsum, c->qin) + Qg - Qr;
+    const float dQr = inflow * c->cQ * pb;
+    dz[3] = dQr;
+    const float kap = pb * c->invKv;
+    const float oM = z[4] * kap, oT = z[5] * kap, oP = z[6] * kap;
+    dz[4] = fmaf(c->Esum, pk, c->MsusUS) - oM;
+    dz[5] = fmaf(c->tA, QsA, fmaf(c->tS, QsS, fmaf(c->tg, Qg, c->tconst))) - oT;
+    dz[6] = fmaf(c->cPP, pk, c->PPrUS) - oP;
+    dz[7] = -c->mu * z[7] * dz[0];
+    dz[8] = -c->mu * z[8] * dz[1];
+    const float r = dQr * (1.0f / Qr);
+    dz[9] = c->bQ * pb * r;
+    dz[10] = c->kM * pk * r;
+    q[0] = Qr; q[1] = oM; q[2] = oT; q[3] = oP;
+}
+
+static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, double rtol_, double atol_,
+                                 int max_steps, double* h_carry, integ_stats* st)
+{
+    enum { NS = 11 };
+    const float T = (float)T_, rtol = (float)rtol_, atol = (float)atol_;
+    float A[6][5], B[6], Ee[6];
+    for (int s = 0; s < 6; ++s) { B[s] = (float)CK_B[s]; Ee[s] = (float)CK_E[s]; for (int j = 0; j < 5; ++j) A[s][j] = (float)CK_A[s][j]; }
+    float z[NS], zt[NS], k[6][NS], kq[4], sq[4];
+    double yq[4] = {0.0, 0.0, 0.0, 0.0};
+    float t = 0.0f, h = (float)*h_carry;
+    int attempts = 0;
+    const double Kv = p->L_reach / (p->a_Q * 8.64 * 10000);
+    if (!(h > 0.0f) || h > T) h = T;
+    dayconst_f c;
+    dayconst_from_params(p, &c);
+    z[0] = (float)y[0]; z[1] = (float)y[1]; z[2] = (float)y[2]; z[3] = (float)y[4];
+    z[4] = (float)y[6]; z[5] = (float)y[8]; z[6] = (float)y[10];
+    z[7] = (float)exp(-p->mu * y[0]); z[8] = (float)exp(-p->mu * y[1]);
+    z[9] = (float)pow(y[4], p->b_Q); z[10] = (float)pow(y[4], p->k_M);
+    int alive = 1;
+    for (int i = 0; i < NS; ++i) if (!(fabsf(z[i]) < 1.0e30f)) alive = 0;      /* (the kernel tests the float states) */
+    if (!alive) { y[5] = y[7] = y[9] = y[11] = NAN; st->poisoned = 1; return; }
+    while (t < T) {
+        const float rem = T - t;
+        float hh = h;
+        if (rem < 2.0f * h) hh = 0.5f * rem;
+        if (rem <= 1.1f * h) hh = rem;
+        const int last_chance = (attempts + 1 >= max_steps);
+        if (last_chance) hh = rem;
+        ode_aug_f32(z, &c, k[0], kq);
+        for (int i = 0; i < 4; ++i) sq[i] = B[0] * kq[i];
+        for (int s = 1; s < 6; ++s) {
+            /* stage weights premultiplied by the step, nested FMAs from the first stage outwards -- the kernel's order */
+            float hw[5];
+            for (int j = 0; j < s; ++j) hw[j] = hh * A[s][j];
+            for (int i = 0; i < NS; ++i) {
+                float acc = z[i];
+                for (int j = 0; j < s; ++j) acc = fmaf(hw[j], k[j][i], acc);
+                zt[i] = acc;
+            }
+            ode_aug_f32(zt, &c, k[s], kq);
+            if (s == 2 || s == 3 || s == 5) for (int i = 0; i < 4; ++i) sq[i] = fmaf(B[s], kq[i], sq[i]);
+        }
+        st->rhs += 6;
+        float err = 0.0f, chk = 0.0f;
+        const float he[6] = {hh * Ee[0], 0.0f, hh * Ee[2], hh * Ee[3], hh * Ee[4], hh * Ee[5]};
+        for (int i = 0; i < AUG_NERR; ++i) {
+            const float e = fmaf(he[0], k[0][i], fmaf(he[2], k[2][i], fmaf(he[3], k[3][i], fmaf(he[4], k[4][i], he[5] * k[5][i]))));
+            if (i >= 3) chk += e;
+            const float sc = fmaf(rtol, fmaxf(fabsf(z[i]), fabsf(fmaf(hh, k[0][i], z[i]))), atol);
+            const float r = fabsf(e) * (1.0f / sc);
+            if (r > err) err = r;
+        }
+        const int bad = !(err < 1.0e30f) || !(fabsf(chk) < 1.0e30f);
+        ++attempts;
+        if (last_chance) st->capped = 1;
+        const int accept = !bad && (err <= 1.0f || last_chance);
+        if (bad && (last_chance || hh <= 1.0e-9f * T)) {
+            for (int i = 0; i < NY; ++i) y[i] = NAN;
+            st->poisoned = 1;
+            *h_carry = (double)h;
+            return;
+        }
+        if (accept) {
+            const float hb0 = hh * B[0], hb2 = hh * B[2], hb3 = hh * B[3], hb5 = hh * B[5];
+            for (int i = 0; i < NS; ++i)
+                z[i] = fmaf(hb5, k[5][i], fmaf(hb3, k[3][i], fmaf(hb2, k[2][i], fmaf(hb0, k[0][i], z[i]))));
+            for (int i = 0; i < 4; ++i) yq[i] = fma(1.0, (double)(hh * sq[i]), yq[i]);
+            t = (hh == rem) ? T : t + hh;
+            st->steps++;
+        } else {
+            st->rejected++;
+        }
+        float fac;
+        if (bad) fac = 0.2f;
+        else {
+            fac = 0.9f * powf(err, -0.2f);               /* err == 0 -> +inf -> 5 */
+            fac = fminf(fmaxf(fac, 0.2f), 5.0f);
+        }
+        h = hh * fac;
+        if (attempts % AUG_RESYNC == 0 && t < T) {
+            const float lq = logf(z[3]);
+            z[9] = expf(c.bQ * lq); z[10] = expf(c.kM * lq);
+        }
+    }
+    *h_carry = (double)h;
+    y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[6] = z[4]; y[8] = z[5]; y[10] = z[6];
+    y[5] = yq[0]; y[7] = yq[1]; y[9] = yq[2]; y[11] = yq[3];
+    y[3] = Kv * pow(y[4], 1.0 - p->b_Q);
+}
+
+/* ------------------------------------------------------------------------------------- */
 /* One member: the SC loop (model.py:365) around the day loop (model.py:491).              */
 
 #define MP(name) (mp[(size_t)SIMPLYP_PM_##name * E + e])
@@ -531,8 +715,10 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
             if (n_integ == SIMPLYP_INTEG_RK4) rk4_day(y, &op, o->step_len, o->substeps, st);
             else if (n_integ == SIMPLYP_INTEG_CASHKARP_AUG)
                 cashkarp_aug_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
+            else if (n_integ == SIMPLYP_INTEG_CASHKARP_AUG_F32)
+                cashkarp_aug_f32_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else cashkarp_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
-            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG) {
+            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG && n_integ != SIMPLYP_INTEG_CASHKARP_AUG_F32) {
                 /* Drift control (not in the reference).  The reference's own equations (:127-131) imply
                  * dVr = dQr * (1-b_Q) L / (a_Q 86400 Qr^b_Q), and Vr0 (:457-459) starts on that curve, so
                  * Vr == L Qr^(1-b_Q) / (a_Q 86400) for all t; Vr has no restoring term and a one-step

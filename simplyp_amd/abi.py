@@ -47,6 +47,19 @@ class GofInfo(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class WbInfo(C.Structure):
+    """simplyp_wb_info of include/simplyp.h."""
+    _fields_ = [('kernel_ms', C.c_double), ('bytes_moved', C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# SIMPLYP_WB_*: the reference's df_summed columns in its order (model.py:866, :886-888, :842-845)
+WB_COLUMNS = ['Q_cumecs', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day', 'SS_mgl', 'TDP_mgl', 'PP_mgl',
+              'TP_mgl', 'TP_kg/day', 'SRP_mgl', 'SRP_kg/day']
+WB_MASK_ALL = (1 << len(WB_COLUMNS)) - 1
+
 GOF_VARS = ['Q', 'SS', 'TDP', 'PP', 'TP', 'SRP']                                      # SIMPLYP_GOF_*
 GOF_STATS = ['N obs', 'NSE', 'log NSE', 'r2', 'Bias (%)', 'nRMSD (%)', 'sum_log_sim', 'sum_relsq']   # SIMPLYP_GOFSTAT_*
 

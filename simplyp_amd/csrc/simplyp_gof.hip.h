@@ -33,7 +33,8 @@ struct GofArgs {
     int col[4];                        // column slots of Qr, Msus_kg/day, TDP_kg/day, PP_kg/day in `out`
     const int32_t* member_of_slot;     // [E] or nullptr
     const double* f_tdp;               // member_params row [E]
-    const double* a_catch;             // reach_params row [S][E]
+    const double* a_catch;             // reach_params row [S][E]; nullptr = the table is a waterbody series (simplyp_waterbody):
+                                       // column 0 holds Q_cumecs, so Q = column 0 and conc = (flux / Q) * 1000/86400
     const int32_t* reach_of;           // [R] reach index of output reach r
     const int32_t* q_ptr;              // [R+1] offsets into q_day / q_obs
     const int32_t* q_day;              // days with a discharge observation
@@ -77,7 +78,7 @@ __device__ __forceinline__ void gof_add(GofAcc& A, double o, double lo, double s
     A.a[7] = __builtin_fma(d, d, A.a[7]);
     A.a[8] += lop;
     A.a[9] = __builtin_fma(lop, lop, A.a[9]);
-    A.a[10] = __builtin_fma(dl, dl, A.a[10]);
+    if (dl == dl) A.a[10] = __builtin_fma(dl, dl, A.a[10]);      // np.sum of a pandas Series skips NaN: log(sim < 0) drops out of :442
     A.a[11] += ls;
     A.a[12] = __builtin_fma(q, q, A.a[12]);
 }
@@ -112,7 +113,9 @@ __global__ __launch_bounds__(64) void simplyp_gof_partial_kernel(const GofArgs g
     const int chunk = blockIdx.y, r = blockIdx.z;
     if (slot >= g.E) return;
     const int member = g.member_of_slot ? g.member_of_slot[slot] : slot;
-    const double A = g.a_catch[(size_t)g.reach_of[r] * g.E + member];
+    // waterbody series: (flux / Q_cumecs) * (1000/86400) = flux / (Q_cumecs * 86.4), i.e. the reach formulas with A = 86.4
+    // for the concentrations and a unit discharge scale
+    const double A = g.a_catch ? g.a_catch[(size_t)g.reach_of[r] * g.E + member] : 86.4;
     const size_t day_stride = (size_t)g.R * g.E;
     const double* qr_col = g.out + (size_t)g.col[0] * g.col_stride + (size_t)r * g.E + slot;
     const double* sh = g.shift + (size_t)r * 12;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(64) void simplyp_gof_partial_kernel(const GofArgs g
         const long long k0 = g.q_ptr[r], n = g.q_ptr[r + 1] - k0;
         const int kb = (int)(k0 + n * chunk / g.n_chunks_q), ke = (int)(k0 + n * (chunk + 1) / g.n_chunks_q);
         const double co = sh[0], clo = sh[6];
-        const double q_scale = A * 1000 / 86400;      // Q = Qr*A*1000/86400 (model.py:784) with the constants folded: 2 ulp
+        const double q_scale = g.a_catch ? A * 1000 / 86400 : 1.0;      // Q = Qr*A*1000/86400 (model.py:784) with the constants folded: 2 ulp
         // batches of GOF_BATCH_Q days: all row loads are issued before the first is consumed (one wave keeps 8 x 512 B
         // in flight; a load-use pair per iteration leaves HBM waiting on latency)
         int k = kb;

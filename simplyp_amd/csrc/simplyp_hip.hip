@@ -19,6 +19,7 @@
 
 #include "simplyp_kernels.hip.h"
 #include "simplyp_gof.hip.h"
+#include "simplyp_waterbody.hip.h"
 
 namespace {
 
@@ -1031,17 +1032,23 @@ static int gof_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mas
                     const int32_t* out_reaches, int32_t n_out_reaches,
                     const double* out, const int32_t* member_of_slot,
                     const double* f_tdp, const double* reach_params,
-                    const double* obs, double* gof, simplyp_gof_info* info)
+                    const double* obs, double* gof, simplyp_gof_info* info, bool waterbody = false)
 {
     if (!ctx) return SIMPLYP_ERR_ARG;
     if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is pending on this context; call simplyp_sync first");
-    if (!dims || dims->E <= 0 || dims->S <= 0 || dims->D <= 0) return fail(ctx, SIMPLYP_ERR_ARG, "bad dims");
-    if (!out || !f_tdp || !reach_params || !obs || !gof) return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
-    const uint32_t need = (1u << SIMPLYP_OUT_QR) | (1u << SIMPLYP_OUT_MSUS_FLUX) | (1u << SIMPLYP_OUT_TDP_FLUX) |
-                          (1u << SIMPLYP_OUT_PP_FLUX);
-    if ((out_mask & need) != need || (out_mask & ~SIMPLYP_MASK_ALL) != 0u)
-        return fail(ctx, SIMPLYP_ERR_ARG, "out_mask must contain Qr, Msus_kg/day, TDP_kg/day and PP_kg/day");
-    const int E = dims->E, S = dims->S, D = dims->D;
+    if (!dims || dims->E <= 0 || (!waterbody && dims->S <= 0) || dims->D <= 0) return fail(ctx, SIMPLYP_ERR_ARG, "bad dims");
+    if (!out || !f_tdp || (!waterbody && !reach_params) || !obs || !gof) return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
+    // the four series the statistics are built from: reach table columns, or (waterbody == true: `out` is a table written by
+    // simplyp_waterbody and `out_mask` its wb_mask) the summed discharge and fluxes
+    const int want[4] = {waterbody ? (int)SIMPLYP_WB_Q_CUMECS : (int)SIMPLYP_OUT_QR,
+                         waterbody ? (int)SIMPLYP_WB_MSUS_FLUX : (int)SIMPLYP_OUT_MSUS_FLUX,
+                         waterbody ? (int)SIMPLYP_WB_TDP_FLUX : (int)SIMPLYP_OUT_TDP_FLUX,
+                         waterbody ? (int)SIMPLYP_WB_PP_FLUX : (int)SIMPLYP_OUT_PP_FLUX};
+    const uint32_t need = (1u << want[0]) | (1u << want[1]) | (1u << want[2]) | (1u << want[3]);
+    if ((out_mask & need) != need || (out_mask & ~(waterbody ? SIMPLYP_WB_MASK_ALL : SIMPLYP_MASK_ALL)) != 0u)
+        return fail(ctx, SIMPLYP_ERR_ARG, waterbody ? "wb_mask must contain Q_cumecs, Msus_kg/day, TDP_kg/day and PP_kg/day"
+                                                    : "out_mask must contain Qr, Msus_kg/day, TDP_kg/day and PP_kg/day");
+    const int E = dims->E, S = waterbody ? 1 : dims->S, D = dims->D;
     const int R = out_reaches ? n_out_reaches : S;
     if (R <= 0 || R > S) return fail(ctx, SIMPLYP_ERR_ARG, "bad n_out_reaches");
     std::vector<int32_t> reach_of(R);
@@ -1093,7 +1100,6 @@ static int gof_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mas
 
     // column slots inside `out`
     simplyp::GofArgs g{};
-    const int want[4] = {SIMPLYP_OUT_QR, SIMPLYP_OUT_MSUS_FLUX, SIMPLYP_OUT_TDP_FLUX, SIMPLYP_OUT_PP_FLUX};
     for (int i = 0; i < 4; ++i) g.col[i] = popcount32(out_mask & ((1u << want[i]) - 1u));
 
     const int groups = (E + simplyp::WAVE - 1) / simplyp::WAVE;
@@ -1144,7 +1150,7 @@ static int gof_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mas
     g.col_stride = (long long)D * R * E;
     g.member_of_slot = member_of_slot;
     g.f_tdp = f_tdp;
-    g.a_catch = reach_params + (size_t)SIMPLYP_PR_A_CATCH * S * E;
+    g.a_catch = waterbody ? nullptr : reach_params + (size_t)SIMPLYP_PR_A_CATCH * S * E;
     g.reach_of = di + o_reach; g.q_ptr = di + o_qp; g.c_ptr = di + o_cp; g.q_day = di + o_qd; g.c_day = di + o_cd;
     g.q_obs = dd + o_qo; g.c_obs = dd + o_co; g.shift = dd + o_sh; g.n_obs = dd + o_n;
     g.n_chunks_q = n_chunks_q;
@@ -1182,6 +1188,83 @@ int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
                 const double* obs, double* gof, simplyp_gof_info* info)
 {
     SIMPLYP_GUARD(ctx, gof_impl(ctx, dims, out_mask, out_reaches, n_out_reaches, out, member_of_slot, f_tdp, reach_params, obs, gof, info))
+}
+
+int simplyp_gof_waterbody(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t wb_mask, const double* wb,
+                          const int32_t* member_of_slot, const double* f_tdp,
+                          const double* obs, double* gof, simplyp_gof_info* info)
+{
+    SIMPLYP_GUARD(ctx, gof_impl(ctx, dims, wb_mask, nullptr, 1, wb, member_of_slot, f_tdp, nullptr, obs, gof, info, true))
+}
+
+static int waterbody_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                          const int32_t* out_reaches, int32_t n_out_reaches,
+                          const double* out, const int32_t* member_of_slot,
+                          const double* f_tdp, const double* reach_params,
+                          const int32_t* sum_reaches, int32_t n_sum,
+                          uint32_t wb_mask, double* wb, simplyp_wb_info* info)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is pending on this context; call simplyp_sync first");
+    if (!dims || dims->E <= 0 || dims->S <= 0 || dims->D <= 0) return fail(ctx, SIMPLYP_ERR_ARG, "bad dims");
+    if (!out || !f_tdp || !reach_params || !sum_reaches || !wb) return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
+    const uint32_t need = (1u << SIMPLYP_OUT_QR) | (1u << SIMPLYP_OUT_MSUS_FLUX) | (1u << SIMPLYP_OUT_TDP_FLUX) |
+                          (1u << SIMPLYP_OUT_PP_FLUX);
+    if ((out_mask & need) != need || (out_mask & ~SIMPLYP_MASK_ALL) != 0u)
+        return fail(ctx, SIMPLYP_ERR_ARG, "out_mask must contain Qr, Msus_kg/day, TDP_kg/day and PP_kg/day");
+    if ((wb_mask & SIMPLYP_WB_MASK_ALL) == 0u || (wb_mask & ~SIMPLYP_WB_MASK_ALL) != 0u)
+        return fail(ctx, SIMPLYP_ERR_ARG, "wb_mask must select 1..%d of the waterbody columns", (int)SIMPLYP_N_WB);
+    const int E = dims->E, S = dims->S, D = dims->D;
+    const int R = out_reaches ? n_out_reaches : S;
+    if (R <= 0 || R > S) return fail(ctx, SIMPLYP_ERR_ARG, "bad n_out_reaches");
+    if (n_sum < 1 || n_sum > simplyp::WB_MAX_REACHES)
+        return fail(ctx, SIMPLYP_ERR_ARG, "n_sum must be in [1, %d] (got %d)", simplyp::WB_MAX_REACHES, n_sum);
+    simplyp::WaterbodyArgs g{};
+    for (int k = 0; k < n_sum; ++k) {
+        const int s = sum_reaches[k];
+        if (s < 0 || s >= S) return fail(ctx, SIMPLYP_ERR_ARG, "sum_reaches[%d] = %d out of range", k, s);
+        if (k > 0 && s <= sum_reaches[k - 1]) return fail(ctx, SIMPLYP_ERR_ARG, "sum_reaches must be strictly ascending");
+        int pos = -1;
+        if (!out_reaches) pos = s;
+        else for (int r = 0; r < R; ++r) if (out_reaches[r] == s) pos = r;
+        if (pos < 0) return fail(ctx, SIMPLYP_ERR_ARG, "reach %d is not among the table's output reaches", s);
+        g.pos[k] = pos; g.reach[k] = s;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int want[4] = {SIMPLYP_OUT_QR, SIMPLYP_OUT_MSUS_FLUX, SIMPLYP_OUT_TDP_FLUX, SIMPLYP_OUT_PP_FLUX};
+    for (int i = 0; i < 4; ++i) g.col[i] = popcount32(out_mask & ((1u << want[i]) - 1u));
+    g.E = E; g.R = R; g.D = D;
+    g.out = out; g.col_stride = (long long)D * R * E;
+    g.n_sum = n_sum;
+    g.member_of_slot = member_of_slot; g.f_tdp = f_tdp;
+    g.a_catch = reach_params + (size_t)SIMPLYP_PR_A_CATCH * S * E;
+    g.wb_mask = wb_mask; g.wb = wb;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    // two member slots per lane (16-byte accesses) when every row of the tables starts 16-byte aligned
+    const bool vec2 = (E % 2 == 0) && (((uintptr_t)out | (uintptr_t)wb) % 16 == 0);
+    if (vec2) hipLaunchKernelGGL(simplyp::simplyp_waterbody_kernel<2>, dim3((unsigned)((E / 2 + 255) / 256), (unsigned)D), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL(simplyp::simplyp_waterbody_kernel<1>, dim3((unsigned)((E + 255) / 256), (unsigned)D), dim3(256), 0, ctx->stream, g);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (info) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+        info->kernel_ms = ms;
+        info->bytes_moved = (int64_t)E * D * (32LL * n_sum + 8LL * popcount32(wb_mask));
+    }
+    return SIMPLYP_OK;
+}
+
+int simplyp_waterbody(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                      const int32_t* out_reaches, int32_t n_out_reaches,
+                      const double* out, const int32_t* member_of_slot,
+                      const double* f_tdp, const double* reach_params,
+                      const int32_t* sum_reaches, int32_t n_sum,
+                      uint32_t wb_mask, double* wb, simplyp_wb_info* info)
+{
+    SIMPLYP_GUARD(ctx, waterbody_impl(ctx, dims, out_mask, out_reaches, n_out_reaches, out, member_of_slot, f_tdp, reach_params,
+                                      sum_reaches, n_sum, wb_mask, wb, info))
 }
 
 void* simplyp_host_alloc(int64_t bytes)

@@ -26,7 +26,7 @@ ABI_SYMBOLS = ['simplyp_abi_version', 'simplyp_device_count', 'simplyp_ctx_creat
                'simplyp_last_error', 'simplyp_ctx_set_stream', 'simplyp_out_bytes', 'simplyp_run',
                'simplyp_run_async', 'simplyp_sync', 'simplyp_plan', 'simplyp_host_alloc', 'simplyp_host_free',
                'simplyp_device_alloc', 'simplyp_device_free', 'simplyp_memcpy_h2d', 'simplyp_memcpy_d2h', 'simplyp_gof',
-               'simplyp_stream_out']
+               'simplyp_stream_out', 'simplyp_waterbody', 'simplyp_gof_waterbody']
 
 _lib = None
 
@@ -38,7 +38,8 @@ class EngineError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, 'simplyp_hip.hip'), os.path.join(CSRC, 'simplyp_kernels.hip.h'),
-            os.path.join(CSRC, 'simplyp_gof.hip.h'), os.path.join(INCLUDE, 'simplyp.h')]
+            os.path.join(CSRC, 'simplyp_gof.hip.h'), os.path.join(CSRC, 'simplyp_waterbody.hip.h'),
+            os.path.join(INCLUDE, 'simplyp.h')]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -89,6 +90,12 @@ def lib():
     L.simplyp_gof.restype = C.c_int
     L.simplyp_gof.argtypes = [vp, C.POINTER(abi.Dims), C.c_uint32, C.POINTER(C.c_int32), C.c_int32, dp, i32p, dp, dp,
                               C.POINTER(C.c_double), dp, C.POINTER(abi.GofInfo)]
+    L.simplyp_waterbody.restype = C.c_int
+    L.simplyp_waterbody.argtypes = [vp, C.POINTER(abi.Dims), C.c_uint32, C.POINTER(C.c_int32), C.c_int32, dp, i32p, dp, dp,
+                                    C.POINTER(C.c_int32), C.c_int32, C.c_uint32, dp, C.POINTER(abi.WbInfo)]
+    L.simplyp_gof_waterbody.restype = C.c_int
+    L.simplyp_gof_waterbody.argtypes = [vp, C.POINTER(abi.Dims), C.c_uint32, dp, i32p, dp, C.POINTER(C.c_double), dp,
+                                        C.POINTER(abi.GofInfo)]
     L.simplyp_stream_out.restype = C.c_int
     L.simplyp_stream_out.argtypes = [vp, vp, C.c_int64]
     L.simplyp_plan.restype = C.c_int
@@ -218,10 +225,15 @@ class Engine(object):
             if dtype is not None:
                 t = t.to(dtype)
             return t.contiguous()
-        t = torch.from_numpy(np.ascontiguousarray(a))
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:
+            a = a.copy()
+        t = torch.from_numpy(a)
         if dtype is not None:
             t = t.to(dtype)
-        return t.to(self.tdev).contiguous()
+        # page-locked sources (engine.pinned_empty) go up as an asynchronous DMA on torch's current stream, which the run
+        # is ordered after (_bind_stream); pageable ones are staged synchronously by torch either way
+        return t.to(self.tdev, non_blocking=True).contiguous()
 
     def run(self, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing_of_member=None,
             out_reaches=None, out=None, member_rhs=None, member_of_slot=None, period_of_day=None, host_out=None):
@@ -332,6 +344,76 @@ class Engine(object):
                                ft.data_ptr(), rp.data_ptr(), obs.ctypes.data_as(C.POINTER(C.c_double)), gof.data_ptr(),
                                C.byref(info))
         self._check(rc, 'simplyp_gof')
+        return gof, info.as_dict()
+
+
+    def _f_tdp(self, f_tdp, E):
+        torch = self.torch
+        ft = self.to_device(np.ascontiguousarray(np.broadcast_to(np.asarray(f_tdp, dtype=np.float64), (E,)))
+                            if not torch.is_tensor(f_tdp) else f_tdp, torch.float64)
+        if tuple(ft.shape) != (E,):
+            raise ValueError("f_tdp must be a scalar or have one entry per member")
+        return ft
+
+    def waterbody(self, out, out_mask, sum_reaches, f_tdp, reach_params, out_reaches=None, member_of_slot=None,
+                  columns=None):
+        """The reference's ``sum_to_waterbody`` (model.py:851-900) for every member, on the device, from the daily table
+        ``out`` of a previous ``run`` (written with ``out_mask``: must contain Qr and the three daily fluxes).
+
+        sum_reaches: zero-based ids of the reaches flagged 'In_final_flux?' (ascending; each must be an output reach of
+        the table); f_tdp scalar or [E]; reach_params [NP_R,S,E]; columns: names from ``abi.WB_COLUMNS`` (default all 11).
+        Returns (wb [n_columns, D, E] device tensor, member axis ordered like ``out``'s, and an info dict)."""
+        torch = self.torch
+        L = lib()
+        rp = self.to_device(reach_params, torch.float64)
+        npr, S, E = rp.shape
+        ncols, D, n_or, E2 = out.shape
+        oreach = _i32(out_reaches)
+        if (E2 != E or ncols != bin(out_mask).count('1') or n_or != (S if oreach is None else len(oreach))
+                or out.dtype != torch.float64 or not out.is_contiguous()):
+            raise ValueError("out %s does not match out_mask / out_reaches / reach_params %s" % (tuple(out.shape), tuple(rp.shape)))
+        cols = list(abi.WB_COLUMNS) if columns is None else list(columns)
+        wb_mask = sum(1 << abi.WB_COLUMNS.index(c) for c in cols)
+        cols = [c for c in abi.WB_COLUMNS if c in cols]
+        sr = _i32(sum_reaches)
+        ft = self._f_tdp(f_tdp, E)
+        wb = torch.empty((len(cols), D, E), dtype=torch.float64, device=self.tdev)
+        info = abi.WbInfo()
+        dims = abi.Dims(E, S, D, 1)
+        with torch.cuda.device(self.tdev):
+            self._bind_stream()
+            rc = L.simplyp_waterbody(self._h, C.byref(dims), int(out_mask),
+                                     None if oreach is None else oreach.ctypes.data_as(C.POINTER(C.c_int32)), n_or,
+                                     out.data_ptr(), None if member_of_slot is None else member_of_slot.data_ptr(),
+                                     ft.data_ptr(), rp.data_ptr(), sr.ctypes.data_as(C.POINTER(C.c_int32)), len(sr),
+                                     wb_mask, wb.data_ptr(), C.byref(info))
+        self._check(rc, 'simplyp_waterbody')
+        d = info.as_dict()
+        d['columns'] = cols
+        return wb, d
+
+    def gof_waterbody(self, wb, columns, obs, f_tdp, member_of_slot=None):
+        """``gof`` for the summed series: wb [n_columns, D, E] from ``waterbody`` (``columns`` as returned there, must hold
+        Q_cumecs and the three summed fluxes); obs [6, D] host array.  Returns (gof [n_stats, 6, 1, E], info)."""
+        torch = self.torch
+        L = lib()
+        ncols, D, E = wb.shape
+        wb_mask = sum(1 << abi.WB_COLUMNS.index(c) for c in columns)
+        if ncols != len(columns) or wb.dtype != torch.float64 or not wb.is_contiguous():
+            raise ValueError("wb %s does not match columns %s" % (tuple(wb.shape), columns))
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        if obs.shape != (len(abi.GOF_VARS), D):
+            raise ValueError("obs must have shape %s, got %s" % ((len(abi.GOF_VARS), D), obs.shape))
+        ft = self._f_tdp(f_tdp, E)
+        gof = torch.empty((len(abi.GOF_STATS), len(abi.GOF_VARS), 1, E), dtype=torch.float64, device=self.tdev)
+        info = abi.GofInfo()
+        dims = abi.Dims(E, 1, D, 1)
+        with torch.cuda.device(self.tdev):
+            self._bind_stream()
+            rc = L.simplyp_gof_waterbody(self._h, C.byref(dims), wb_mask, wb.data_ptr(),
+                                         None if member_of_slot is None else member_of_slot.data_ptr(), ft.data_ptr(),
+                                         obs.ctypes.data_as(C.POINTER(C.c_double)), gof.data_ptr(), C.byref(info))
+        self._check(rc, 'simplyp_gof_waterbody')
         return gof, info.as_dict()
 
 

@@ -138,10 +138,11 @@ def topology(p_struc, p):
     return (np.asarray(up_ptr, dtype=np.int32), np.asarray(up_idx, dtype=np.int32), up_lists)
 
 
-def member_params(p, p_LU, E=1, overrides=None):
-    """[NP_M, E] fp64.  ``overrides``: flat name (see PM_NAMES) -> scalar or array[E]."""
+def member_params(p, p_LU, E=1, overrides=None, alloc=np.empty):
+    """[NP_M, E] fp64.  ``overrides``: flat name (see PM_NAMES) -> scalar or array[E].  ``alloc(shape, dtype)``: where
+    the array lives (``engine.pinned_empty`` = page-locked host memory, so the upload is an asynchronous DMA)."""
     overrides = overrides or {}
-    out = np.empty((NP_M, E), dtype=np.float64)
+    out = alloc((NP_M, E), np.float64)
     for i, (name, src) in enumerate(PM_SPEC):
         if name in overrides:
             out[i, :] = np.asarray(overrides[name], dtype=np.float64)
@@ -154,12 +155,13 @@ def member_params(p, p_LU, E=1, overrides=None):
     return out
 
 
-def reach_params(p_SC, p, E=1, overrides=None):
-    """[NP_R, S, E] fp64.  ``overrides``: name (see PR_NAMES) -> array broadcastable to [S, E]."""
+def reach_params(p_SC, p, E=1, overrides=None, alloc=np.empty):
+    """[NP_R, S, E] fp64.  ``overrides``: name (see PR_NAMES) -> array broadcastable to [S, E].  ``alloc``: see
+    ``member_params``."""
     overrides = overrides or {}
     scs = sc_list(p)
     S = len(scs)
-    out = np.empty((NP_R, S, E), dtype=np.float64)
+    out = alloc((NP_R, S, E), np.float64)
     for i, name in enumerate(PR_NAMES):
         if name in overrides:
             out[i] = np.broadcast_to(np.asarray(overrides[name], dtype=np.float64), (S, E))
@@ -169,13 +171,18 @@ def reach_params(p_SC, p, E=1, overrides=None):
     return out
 
 
-def forcing_arrays(met_df, snow=False):
+def forcing_arrays(met_df, snow=False, alloc=None):
     """([1, 2, D] fp64 with rows P, PET ; doy[D] int32) from the met dataframe (model.py:497-498, :550).
     ``snow=True``: [1, 3, D] with rows Precipitation, PET, T_air -- the raw met columns the in-kernel snow module
     (opts.snow = 1; reference inputs.py:159-210) turns into each member's own P."""
     rows = ['Precipitation', 'PET', 'T_air'] if snow else ['P', 'PET']
     f = np.stack([met_df[c].to_numpy(dtype=np.float64) for c in rows])[None]
     doy = np.asarray(met_df.index.dayofyear, dtype=np.int32)
+    if alloc is not None:
+        fa, da = alloc(f.shape, np.float64), alloc(doy.shape, np.int32)
+        fa[...] = f
+        da[...] = doy
+        return fa, da
     return np.ascontiguousarray(f), np.ascontiguousarray(doy)
 
 

@@ -230,7 +230,8 @@ def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len
 
 def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
                           outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True,
-                          reduce=None, obs_dict=None, keep_daily=True, snow_in_kernel=None, forcing_of_member=None):
+                          reduce=None, obs_dict=None, keep_daily=True, snow_in_kernel=None, forcing_of_member=None,
+                          waterbody=None, waterbody_obs=None):
     """Run an ensemble of parameter sets through the engine in one call.
 
     ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
@@ -253,6 +254,14 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     uses ``p['f_TDP']`` or ``overrides['f_TDP']`` (array[E]).  ``keep_daily=False`` drops the daily table once the
     statistics exist (``data`` is None): the 44 GB of a 100 000-member run never leave the device.
 
+    ``waterbody``: the reference's ``sum_to_waterbody`` (model.py:851-900) for every member, on the device: ``True`` sums
+    the sub-catchments flagged ``p_struc['In_final_flux?'] == 1``, a list sums the given sub-catchment ids.  Like the
+    reference, fewer than two reaches give ``None`` (:872, :895).  The result comes back under ``'waterbody'`` =
+    dict(columns (the reference's 11: ``abi.WB_COLUMNS``), reaches, data[11, D, E], info); needs daily rows and adds the
+    four flux columns / the summed reaches to the outputs when missing.  ``waterbody_obs``: DataFrame of observations
+    at the waterbody's inflow (columns among Q, SS, TDP, PP, TP, SRP): the members' goodness-of-fit table of the summed
+    series under ``['waterbody']['gof']``.
+
     Returns ``dict(columns, reaches, data[n_cols, D or n_periods, n_reaches, E], status[E], stats)``; ``data``
     and ``status`` are numpy arrays, or device tensors when ``to_host`` is False.
     The caller's ``p_LU``/``p_SC`` are edited in place exactly as by ``run_simply_p``.
@@ -271,8 +280,10 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
             raise ValueError("cannot infer the ensemble size: give n_members or override arrays of one length")
         n_members = sizes.pop()
     E = int(n_members)
-    mp = marshal.member_params(p, p_LU, E, m_over)
-    rp = marshal.reach_params(p_SC, p, E, r_over)
+    # the SoA arrays are marshalled straight into page-locked host memory: the uploads are asynchronous DMA transfers
+    pin = engine.pinned_empty
+    mp = marshal.member_params(p, p_LU, E, m_over, alloc=pin)
+    rp = marshal.reach_params(p_SC, p, E, r_over, alloc=pin)
     if snow_in_kernel is None:
         snow_in_kernel = 'f_DDSM' in m_over or 'D_snow_0' in m_over
     met_sets = list(met_df) if isinstance(met_df, (list, tuple)) else [met_df]
@@ -293,7 +304,21 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     parts = [marshal.forcing_arrays(m, snow=snow_in_kernel) for m in met_sets]
     forcing, doy = np.ascontiguousarray(np.concatenate([f for f, _ in parts], axis=0)), parts[0][1]
     cols = list(outputs) if outputs is not None else list(marshal.REACH5_COLUMNS)
-    if obs_dict is not None:
+    wb_reaches = None
+    if waterbody is not None and waterbody is not False:
+        if reduce is not None:
+            raise ValueError("the waterbody sum needs the daily series: waterbody cannot be combined with reduce")
+        if waterbody is True:
+            flags = p_struc['In_final_flux?']
+            wb_reaches = [int(r) for r in flags[flags == 1].index.values]                    # model.py:867
+            if len(wb_reaches) > len(scs):                                                       # :871-872
+                raise ValueError("Mismatch between the number of subcatchments in the 'Setup' parameter sheet \n(parameter 'n_SC') and in the 'Reach_structure' parameter sheet")
+        else:
+            wb_reaches = sorted(int(r) for r in waterbody)
+        print('Sub-catchments flowing directly into receiving waterbody: %s' % np.asarray(wb_reaches))   # :874
+        if out_reaches is not None:
+            out_reaches = list(out_reaches) + [r for r in wb_reaches if r not in out_reaches]
+    if obs_dict is not None or wb_reaches is not None:
         if reduce is not None:
             raise ValueError("goodness of fit needs the daily series: obs_dict cannot be combined with reduce")
         cols += [c for c in ('Qr', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day') if c not in cols]
@@ -317,8 +342,15 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
 
     eng = engine.get_engine(device)
     rp_d = eng.to_device(rp)
+    # to_host: the table is delivered into page-locked host memory while the kernel runs (simplyp_stream_out) -- unless the
+    # caller only wants the statistics (keep_daily=False)
+    host_out = None
+    if to_host and (keep_daily or obs_dict is None):
+        n_or_ = len(scs) if oreach is None else len(oreach)
+        rows_ = len(met_df) if periods is None else len(periods)
+        host_out = pin((bin(mask).count('1'), rows_, n_or_, E))
     out_d, status_d, stats = eng.run(forcing, doy, mp, rp_d, up_ptr, up_idx, opts, out_reaches=oreach,
-                                     period_of_day=period_of_day, forcing_of_member=forcing_of_member)
+                                     period_of_day=period_of_day, forcing_of_member=forcing_of_member, host_out=host_out)
     marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)
     reaches = scs if out_reaches is None else list(out_reaches)
     res = dict(columns=marshal.columns_of_mask(mask), reaches=reaches, periods=periods, stats=stats,
@@ -330,7 +362,24 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
                               member_of_slot=stats.get('member_of_slot') if opts.out_slot_order else None)
         res['gof'] = dict(stats=list(abi.GOF_STATS), variables=list(abi.GOF_VARS), info=info,
                           data=gof_d.cpu().numpy() if to_host else gof_d)
-        if not keep_daily:
-            out_d = None
-    res['data'] = None if out_d is None else (out_d.cpu().numpy() if to_host else out_d)
+    if wb_reaches is not None:
+        if len(wb_reaches) > 1:
+            mos = stats.get('member_of_slot') if opts.out_slot_order else None
+            ft = p['f_TDP'] if f_tdp is None else f_tdp
+            wb_d, winfo = eng.waterbody(out_d, mask, [scs.index(r) for r in wb_reaches], ft, rp_d, out_reaches=oreach,
+                                        member_of_slot=mos)
+            res['waterbody'] = dict(columns=winfo['columns'], reaches=wb_reaches, info=winfo,
+                                    data=wb_d.cpu().numpy() if to_host else wb_d)
+            if waterbody_obs is not None:
+                from . import visualise_results as vr
+                wobs = vr.observation_array({0: waterbody_obs}, [0], met_df.index)[0]
+                g_d, ginfo = eng.gof_waterbody(wb_d, winfo['columns'], wobs, ft, member_of_slot=mos)
+                res['waterbody']['gof'] = dict(stats=list(abi.GOF_STATS), variables=list(abi.GOF_VARS), info=ginfo,
+                                               data=g_d.cpu().numpy() if to_host else g_d)
+        else:
+            print('One or fewer reaches were selected to be included in the sum, check your reach structure parameters')   # :896
+            res['waterbody'] = None
+    if obs_dict is not None and not keep_daily:
+        out_d = None
+    res['data'] = None if out_d is None else (host_out if to_host else out_d)
     return res

@@ -44,7 +44,7 @@ def test_struct_layouts(tmp_path):
     """ctypes mirrors vs the C compiler's view of include/simplyp.h (sizeof / offsetof of every field)."""
     import subprocess
     structs = {'simplyp_dims': abi.Dims, 'simplyp_opts': abi.Opts, 'simplyp_stats': abi.Stats,
-               'simplyp_gof_info': abi.GofInfo}
+               'simplyp_gof_info': abi.GofInfo, 'simplyp_wb_info': abi.WbInfo}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HEADER, 'int main(void){']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
