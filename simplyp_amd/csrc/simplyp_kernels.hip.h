@@ -467,7 +467,13 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         for (int i = 0; i < 4; ++i) yq[i] = __builtin_nan("");
     }
 
-    while (__any(alive)) {
+    // Loop nest: the inner loop is one attempt per trip and has a single back edge; what happens only every RESYNC_EVERY-th
+    // attempt (re-evaluating the auxiliary states) sits in the outer loop.  Same sequence of operations as one flat loop with
+    // the resync inside -- but with the rare block as a second latch of the attempt loop the register allocator split the
+    // loop-carried state across the back edge and paid ~40 register copies per attempt.
+    bool any_alive = __any(alive);
+    while (any_alive) {
+    do {
         ++cnt.wave_trips;                 // one attempt issued for the whole wavefront, whoever still needs it
         const R rem = T - t;
         R hh = h;
@@ -567,22 +573,22 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         if (last_chance && alive) cnt.capped = true;
         t = accept ? ((hh == rem) ? T : t + hh) : t;
         // State update in place, only for lanes that accepted: y += (m h b1) k1 + (m h b3) k3 + (m h b4) k4 + (m h b6) k6 with
-        // m = 1 / 0.  0 * NaN would poison a lane that merely rejected a non-finite trial, so the rare wave that has such
-        // a lane takes the select path instead; that is also where a lane gives up.
-        if (__any(alive && bad)) {
+        // m = 1 / 0.  0 * NaN would poison a lane that merely rejected a non-finite trial, so the rare wave that has such a
+        // lane first zeroes that lane's stage derivatives (0 * 0 leaves its state alone); that is also where a lane gives up.
+        // ONE update expression for every lane and every wave: a member's result does not depend on its wave mates, and the
+        // loop-carried state has a single definition (two alternative update paths cost ~25 register copies per attempt).
+        const bool any_bad = __any(alive && bad);
+        if (any_bad) {
             give_up = alive && bad && (last_chance || hh <= (R)1.0e-9 * T);
             if (alive && bad) fac = 0.2f;
-            const R hb1 = hh * b1, hb3 = hh * b3, hb4 = hh * b4, hb6 = hh * b6;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                // (the same expression as on the common path, so that a member's result does not depend on its wave mates)
-                const R yn = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], sp_fma(hb1, k1[i], y[i]))));
-                y[i] = give_up ? (R)__builtin_nanf("") : (accept ? yn : y[i]);
+                k1[i] = bad ? (R)0 : k1[i]; k3[i] = bad ? (R)0 : k3[i]; k4[i] = bad ? (R)0 : k4[i]; k6[i] = bad ? (R)0 : k6[i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) yq[i] = give_up ? __builtin_nan("") : (accept ? yq[i] + (double)dq[i] : yq[i]);
-            if (give_up) { cnt.poisoned = true; gave_up_today = true; }
-        } else {
+            for (int i = 0; i < 4; ++i) dq[i] = bad ? (R)0 : dq[i];
+        }
+        {
             const R m = accept ? hh : (R)0;
             const R hb1 = m * b1, hb3 = m * b3, hb4 = m * b4, hb6 = m * b6;
 #pragma unroll
@@ -591,12 +597,23 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 #pragma unroll
             for (int i = 0; i < 4; ++i) yq[i] = __builtin_fma((double)mq, (double)dq[i], yq[i]);
         }
+        if (any_bad) {
+            if (give_up) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) y[i] = (R)__builtin_nanf("");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yq[i] = __builtin_nan("");
+                cnt.poisoned = true; gave_up_today = true;
+            }
+        }
         h = alive ? hh * (R)fac : h;
         alive = alive && !give_up && (t < T);
+        any_alive = __any(alive);
+    } while (any_alive && (SYS::RESYNC_EVERY == 0 || (trip % SYS::RESYNC_EVERY) != 0));
         if (SYS::RESYNC_EVERY > 0) {
             // after every RESYNC_EVERY-th attempt of the day: a wave-uniform test (see `trip`), while the schedule stays a
             // function of the lane's own history -- results do not depend on which members share a wavefront
-            if ((trip % SYS::RESYNC_EVERY) == 0) {
+            if (any_alive && (trip % SYS::RESYNC_EVERY) == 0) {
                 if (alive) SYS::resync(y, c);
             }
         }

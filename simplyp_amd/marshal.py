@@ -171,6 +171,29 @@ def reach_params(p_SC, p, E=1, overrides=None, alloc=np.empty):
     return out
 
 
+def validate_ensemble(mp, rp, scs):
+    """The reference's input checks (model.py:321-335, :355-357) for every member of an ensemble: per-member overrides of
+    the land-use fractions or the erosion-window days skip ``prologue`` (which sees the workbook values only), and the
+    kernel would integrate such members where the reference raises.  Vectorised over [S, E]; the message names the first
+    offending member."""
+    r = lambda name: rp[PR_NAMES.index(name)]
+    f_A = r('f_IG') + r('f_Ar')                                                                  # :318
+    f_NC_A = (r('f_Ar') * r('f_NC_Ar')) + (r('f_NC_IG') * r('f_IG'))                             # :319
+    bad = (f_A + r('f_S')) != 1                                                                  # :322 (exact, like the reference)
+    if bad.any():
+        s, e = np.argwhere(bad)[0]
+        raise ValueError('Land use proportions do not add to 1 in SC %s (ensemble member %d)' % (scs[s], e))
+    bad = (f_NC_A > 0) & (r('f_NC_S') > 0)                                                       # :325-329
+    if bad.any():
+        s, e = np.argwhere(bad)[0]
+        raise ValueError("Sub-catchment %s has 2 kinds of newly-converted land (ensemble member %d);\n\
+                only one permitted (Semi-natural or agricultural, agricultural can be both arable & IG)" % (scs[s], e))
+    for season in ['spr', 'aut']:                                                                # :355-357
+        d = mp[PM_NAMES.index('d_maxE_%s' % season)]
+        assert bool(((30 < d) & (d < 335)).all()), \
+            "'d_maxE_%s' must be between 30 and 335 (ensemble member %d)" % (season, int(np.argmax(~((30 < d) & (d < 335)))))
+
+
 def forcing_arrays(met_df, snow=False, alloc=None):
     """([1, 2, D] fp64 with rows P, PET ; doy[D] int32) from the met dataframe (model.py:497-498, :550).
     ``snow=True``: [1, 3, D] with rows Precipitation, PET, T_air -- the raw met columns the in-kernel snow module

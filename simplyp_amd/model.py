@@ -284,6 +284,8 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     pin = engine.pinned_empty
     mp = marshal.member_params(p, p_LU, E, m_over, alloc=pin)
     rp = marshal.reach_params(p_SC, p, E, r_over, alloc=pin)
+    if m_over or r_over:
+        marshal.validate_ensemble(mp, rp, scs)       # the reference's checks, for every member (model.py:321-335, :355-357)
     if snow_in_kernel is None:
         snow_in_kernel = 'f_DDSM' in m_over or 'D_snow_0' in m_over
     met_sets = list(met_df) if isinstance(met_df, (list, tuple)) else [met_df]

