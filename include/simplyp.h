@@ -141,7 +141,10 @@ typedef struct {
                                 SIMPLYP_PM_D_SNOW_0 (inputs.py:183-208), so an ensemble can perturb the snow parameters
                                 without one forcing set per member.  Same arithmetic, same order: P is bit-identical
                                 to the host function's.                                                          */
-    int32_t  reserved;
+    int32_t  lanes_per_wave; /* member slots per 64-lane wavefront: 0 = auto (64, except that a single-reach ensemble too small
+                                to fill the chip's SIMDs with full waves under an adaptive integrator is spread over more,
+                                thinner waves: a wave's day costs the attempts of its slowest lane), 1..64 = as given.
+                                Results are unchanged bit for bit.                                               */
 } simplyp_opts;
 
 typedef struct {
@@ -155,6 +158,8 @@ typedef struct {
     int32_t  n_launches;     /* kernel launches issued (one per routing stage)             */
     int32_t  balanced;       /* 1 when the cost-sorted member order was used                */
     int32_t  queued;         /* 1 when the time-chunk task queue kernel ran                  */
+    int32_t  lanes_per_wave; /* member slots per wavefront the run used (opts.lanes_per_wave)                     */
+    int32_t  reserved;
     int32_t  streamed_chunks;/* simplyp_stream_out: time chunks whose device-to-host copy started while the kernel was still
                                 running (0 = the table was copied after the last launch)                           */
     double   d2h_tail_ms;    /* simplyp_stream_out: device time between the end of the last launch and the last output

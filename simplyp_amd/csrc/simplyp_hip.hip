@@ -66,6 +66,7 @@ struct simplyp_ctx {
     int streamed_chunks = 0;            // chunks whose copy started before the kernel had finished
     bool copy_pending = false;
     std::chrono::steady_clock::time_point t_begin;
+    int lanes = 64;           // member slots per wavefront of the last run
     int queued = 0;           // last run used the task-queue kernel
     int n_simd_slots = 1024;  // CUs x 4 SIMDs: wave slots at one resident wave per SIMD
     int balanced = 0;         // last run used the cost-sorted member order
@@ -651,7 +652,16 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     a.out_by_slot = 0;
     a.params_by_slot = 0;
     a.member_rhs = member_rhs_evals;
-    const unsigned gx = (unsigned)((E + simplyp::WAVE - 1) / simplyp::WAVE);
+    // Member slots per wavefront.  64 unless the ensemble cannot fill the chip with full waves: a single-reach ensemble under an
+    // adaptive integrator is then spread over as many waves as there are SIMDs (a wave's day costs its slowest lane's attempts;
+    // idle SIMDs cost nothing).  Results do not depend on it (members are independent).
+    int lanes = simplyp::WAVE;
+    if (opts->lanes_per_wave > 0) lanes = std::min<int>(simplyp::WAVE, opts->lanes_per_wave);
+    else if (opts->integrator != SIMPLYP_INTEG_RK4 && S == 1 && (E + simplyp::WAVE - 1) / simplyp::WAVE < ctx->n_simd_slots)
+        lanes = std::max(1, (E + ctx->n_simd_slots - 1) / ctx->n_simd_slots);
+    a.lanes = lanes;
+    ctx->lanes = lanes;
+    const unsigned gx = (unsigned)((E + lanes - 1) / lanes);
     const bool snow = opts->snow != 0;
     // one launch of the chain kernel: k.chain_ptr / k.chain_reach describe n_chains mutually independent chains
     auto launch_chains = [&](const simplyp::KernelArgs& k, unsigned n_chains, unsigned n_windows = 1u) -> int {
@@ -990,11 +1000,12 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->rhs_evals = c[0]; stats->steps = c[1]; stats->rejected = c[2];
         stats->kernel_ms = ms;
         // lanes doing useful work per issued attempt: (attempts summed over lanes) / (64 x wave-level attempts)
-        stats->simt_efficiency = c[3] ? (double)(c[0] / 6) / (64.0 * (double)c[3]) : 1.0;
+        stats->simt_efficiency = c[3] ? (double)(c[0] / 6) / (64.0 * (double)c[3]) : 1.0;     // (of all 64 lanes, also when a wave carries fewer members)
         stats->pilot_ms = ctx->balanced ? ms_pilot : 0.0;
         stats->n_launches = ctx->n_launches;
         stats->balanced = ctx->balanced;
         stats->queued = ctx->queued;
+        stats->lanes_per_wave = ctx->lanes;
         stats->streamed_chunks = copied ? ctx->streamed_chunks : 0;
         stats->d2h_tail_ms = copied ? ms_tail : 0.0;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();

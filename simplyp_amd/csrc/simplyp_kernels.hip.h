@@ -30,6 +30,7 @@ constexpr int TILE_D = 256;     // days of forcing staged in LDS at a time (256*
 
 struct KernelArgs {
     int E, S, D, n_sets;
+    int lanes;                      // member slots per wavefront (1..64): lane l of group g owns slot g*lanes + l, lanes >= `lanes` idle
     int D_stride;                   // row stride of `forcing` in days (D of the full run)
     const int* perm;                // [E] member handled by each lane slot, or nullptr = identity
     int out_by_slot;                // 1: `out` columns are lane slots (coalesced), 0: member ids
@@ -423,7 +424,7 @@ struct CkCounters { unsigned rhs, steps, rejected, wave_trips; bool capped, pois
 template <class SYS>
 __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double (&yq)[4], const typename SYS::dayconst& c,
                                        const double T_, const double rtol_, const double atol_, int max_steps, double& h_carry,
-                                       CkCounters& cnt)
+                                       CkCounters& cnt, const bool lane_active)
 {
     typedef typename SYS::real R;       // working precision of the stages (the daily integrals yq stay fp64)
     constexpr int NS = SYS::NS;
@@ -466,6 +467,9 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 #pragma unroll
         for (int i = 0; i < 4; ++i) yq[i] = __builtin_nan("");
     }
+    // a lane without a member of its own (ragged last group, or a wave that carries fewer than 64 members on purpose) shadows a
+    // valid slot for its addresses but must not keep the wave in the attempt loop
+    alive = alive && lane_active;
 
     // Loop nest: the inner loop is one attempt per trip and has a single back edge; what happens only every RESYNC_EVERY-th
     // attempt (re-evaluating the auxiliary states) sits in the outer loop.  Same sequence of operations as one flat loop with
@@ -874,7 +878,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));    // Vr = Kv Qr^(1-b_Q), see oracle
                 } else if (INTEG == SIMPLYP_INTEG_CASHKARP) {
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
-                    ck_day<SysLiteral>(y, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
+                    ck_day<SysLiteral>(y, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
@@ -891,7 +895,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     z[7] = (float)ea; z[8] = (float)es; z[9] = (float)pb0; z[10] = (float)pk0;
                     const DayConstF cf(c);
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
-                    ck_day<SysAugF>(z, yq, cf, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
+                    ck_day<SysAugF>(z, yq, cf, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
@@ -905,7 +909,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     const double lq0 = sp_log(y[4]);
                     sp_exp2(b_Q * lq0, k_M * lq0, z[9], z[10]);
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
-                    ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt);
+                    ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
@@ -997,6 +1001,14 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
     if (active && a.member_rhs) atomicAdd(&a.member_rhs[e], n_rhs);      // several chains / time chunks per member
 }
 
+// Member slot of a lane: group g carries a.lanes consecutive slots; the other lanes of the wave get E (= no member).
+// Fewer than 64 members per wave is what a small ensemble wants: a wave's day costs the attempts of its slowest lane, and an
+// ensemble that cannot fill the chip's 1024 SIMDs with full waves loses nothing by spreading over more, thinner ones.
+__device__ __forceinline__ int slot_of_lane(const KernelArgs& a, int group, int lane)
+{
+    return lane < a.lanes ? group * a.lanes + lane : a.E;
+}
+
 // fp64 schemes need ~500 registers for the Cash-Karp stages (one wave per SIMD); the fp32 scheme is asked to fit two
 template <int INTEG, bool SNOW>
 __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs a)
@@ -1013,10 +1025,10 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs
         w.doy = a.doy ? a.doy + off : nullptr;
         w.member_rhs = a.member_rhs + (size_t)blockIdx.z * a.E;
         w.route = a.route ? a.route + (size_t)blockIdx.z * a.win_route_stride : nullptr;
-        run_slot<INTEG, SNOW>(w, s_P, s_E, s_T, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+        run_slot<INTEG, SNOW>(w, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
         return;
     }
-    run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, threadIdx.x, blockIdx.x * WAVE + threadIdx.x, a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+    run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1111,7 +1123,7 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int d_begin = c * q.chunk_days;
             const int d_end = min(a.D, d_begin + q.chunk_days);
-            run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, lane, g * WAVE + lane, q.task_reach + pair, 1, d_begin, d_end,
+            run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
                             q.ckpt + (size_t)s * CKPT_N * (size_t)a.E);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

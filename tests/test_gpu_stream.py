@@ -216,3 +216,24 @@ def test_bench_starts_its_own_ranks(tmp_path):
         assert j['config']['members_total'] == total and j['config']['members_per_gpu'] == per_gpu
         assert j['value'] > 0 and j['parity']['timed_run_sample']['max_rel_err_vs_oracle'] < 1e-7
         assert j['parity']['timed_run_sample']['host_table_equals_device_table'] is True
+
+
+@pytest.mark.parametrize('lanes', [1, 13, 32])
+def test_thin_waves_are_bitwise_identical(engine0, lanes):
+    """opts.lanes_per_wave: a wave that carries fewer than 64 members (what a small ensemble gets automatically, so that
+    its members spread over the chip's SIMDs) computes the same bits: chain kernel and time-chunk queue, ragged last group."""
+    import torch
+    for name, E, solver in (('tarland_2004_dynamic', 150, dict(time_chunk_days=-1)), ('tarland_2004_dynamic', 150, dict(time_chunk_days=256)),
+                            ('chain4_val_2004', 70, None)):
+        m = perturbed(name, E, out_mask=marshal.MASK_REACH5, solver=dict(solver or {}, lanes_per_wave=64))
+        ref, rs, rst = run(engine0, m)
+        assert rst['lanes_per_wave'] == 64
+        m['opts'].lanes_per_wave = lanes
+        got, gs, gst = run(engine0, m)
+        assert gst['lanes_per_wave'] == lanes and gst['rhs_evals'] == rst['rhs_evals']
+        assert bool(torch.equal(got, ref)) and bool(torch.equal(gs, rs))
+    # auto: a single-reach ensemble that cannot fill the chip is spread; a reach network keeps full waves
+    m = perturbed('tarland_2004_dynamic', 3000, out_mask=marshal.MASK_REACH5)
+    assert run(engine0, m)[2]['lanes_per_wave'] == 3
+    m = perturbed('chain4_val_2004', 300, out_mask=marshal.MASK_REACH5)
+    assert run(engine0, m)[2]['lanes_per_wave'] == 64
