@@ -174,6 +174,7 @@ def main():
     ncols = bin(opts.out_mask).count('1')
     rows = opts.n_periods if opts.n_periods > 0 else D
 
+    numa_node = engine.bind_host_thread_to_gpu_numa_node(local_rank) if world > 1 else None      # staging buffers next to the GPU's PCIe root
     eng = engine.get_engine(local_rank)
     # inputs: marshalled into pinned host arrays, uploaded once (resident in HBM before the timed region)
     pinned = {}
@@ -286,7 +287,7 @@ def main():
                          "d2h_tail_ms": float(np.mean([s['d2h_tail_ms'] for s in step_stats])),
                          "streamed_chunks": int(step_stats[-1]['streamed_chunks']),
                          "d2h_gbs_over_run": None if host_out is None else out_bytes / (float(np.mean([s['wall_ms'] for s in step_stats])) * 1e-3) / 1e9,
-                         "pcie_spec_gbs": PCIE_SPEC_GBS, "note": stream_note},
+                         "pcie_spec_gbs": PCIE_SPEC_GBS, "host_numa_node": numa_node, "note": stream_note},
             "occupancy": {"waves_per_gpu": waves, "simd_slots": 1024, "rounds": waves / 1024.0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,

@@ -560,6 +560,11 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
 /* ------------------------------------------------------------------------------------- */
 /* One member: the SC loop (model.py:365) around the day loop (model.py:491).              */
 
+/* Optional trace for tools/probe_async.py: attempted steps (accepted + rejected) of every member and day, [E][D] uint16,
+ * single-reach runs.  NULL = off. */
+static uint16_t* g_day_attempts = NULL;
+void simplyp_oracle_set_trace(uint16_t* day_attempts) { g_day_attempts = day_attempts; }
+
 #define MP(name) (mp[(size_t)SIMPLYP_PM_##name * E + e])
 #define RP(name, s) (rp[((size_t)SIMPLYP_PR_##name * S + (s)) * E + e])
 
@@ -712,6 +717,7 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
             op.TDPg = MP(TDPG); op.E_PP = MP(E_PP); op.P_inactive = P_inactive; op.Qg_min = Qg_min;
 
             /* model.py:640 -- the one place that is not a restatement (see header) */
+            const uint64_t attempts_before = st->steps + st->rejected;
             if (n_integ == SIMPLYP_INTEG_RK4) rk4_day(y, &op, o->step_len, o->substeps, st);
             else if (n_integ == SIMPLYP_INTEG_CASHKARP_AUG)
                 cashkarp_aug_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
@@ -725,6 +731,7 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
                  * integrator random-walks off it.  Re-impose it once per day. */
                 y[3] = L_reach * pow(y[4], 1.0 - b_Q) / (a_Q * 8.64 * 10000);
             }
+            if (g_day_attempts && S == 1) g_day_attempts[(size_t)e * D + idx] = (uint16_t)(st->steps + st->rejected - attempts_before);
             const double* res = y;                                                               /* :643 */
             for (int i = 0; i < NY; ++i) if (!isfinite(res[i])) stat |= SIMPLYP_STATUS_NONFINITE;
 

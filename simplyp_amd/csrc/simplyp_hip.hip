@@ -436,6 +436,7 @@ int simplyp_ctx_create(int device, simplyp_ctx** out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->n_simd_slots = prop.multiProcessorCount * 4;
+
     }
     if (err != hipSuccess) {
         fail(nullptr, SIMPLYP_ERR_DEVICE, "context creation on device %d failed: %s", device, hipGetErrorString(err));
@@ -881,7 +882,11 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
             k.route_slot = dq + off_qslot;
             k.chain_ptr = nullptr; k.chain_reach = nullptr;
             const long long n_tasks = (long long)pair_idx.size() * G;
+#ifdef SIMPLYP_EXP_LDS_DAYCONST
+            unsigned workers = (unsigned)std::min<long long>(n_tasks, 2LL * ctx->n_simd_slots);       // experiment: two resident waves per SIMD
+#else
             unsigned workers = (unsigned)std::min<long long>(n_tasks, ctx->n_simd_slots);
+#endif
             if (const char* w_env = getenv("SIMPLYP_QUEUE_WORKERS")) workers = std::max(1u, std::min(workers, (unsigned)strtoul(w_env, nullptr, 10)));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 #define SIMPLYP_LAUNCH_QUEUE(INTEG)                                                                                                       \

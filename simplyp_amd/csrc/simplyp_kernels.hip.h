@@ -348,6 +348,72 @@ struct SysAug {
 };
 
 
+#ifdef SIMPLYP_EXP_LDS_DAYCONST
+// EXPERIMENT (tools/build_variant.sh; not in the product build): the 27 day constants live in LDS ([27][64] doubles per wave,
+// 13.8 KB) and the right-hand side reads each one where it is used, so that they do not occupy 54 registers across the attempt
+// loop -- the precondition for fitting two waves per SIMD (<= 256 registers).
+enum { DC_c0, DC_aE, DC_mu, DC_fc, DC_inv_d, DC_invTsA, DC_invTsS, DC_invTg, DC_Qgmin, DC_inv_dg, DC_beta, DC_fA, DC_fS, DC_qin,
+       DC_omb, DC_cQ, DC_bQ, DC_kM, DC_Esum, DC_MsusUS, DC_tA, DC_tS, DC_tg, DC_tconst, DC_cPP, DC_PPrUS, DC_invKv, DC_N };
+typedef const volatile __attribute__((address_space(3))) double* lds_cvd_ptr;
+struct DayConstLds {
+    lds_cvd_ptr p;                  // &s_dc[lane] in the LDS address space (ds_read_b64, not a flat load); constant k at p[k * WAVE]
+    __device__ __forceinline__ double operator()(int k) const { return p[k * WAVE]; }
+};
+__device__ __forceinline__ void store_dayconst(double* s, int lane, const DayConst& c)
+{
+    double* p = s + lane;
+#define DC_PUT(n) p[DC_##n * WAVE] = c.n;
+    DC_PUT(c0) DC_PUT(aE) DC_PUT(mu) DC_PUT(fc) DC_PUT(inv_d) DC_PUT(invTsA) DC_PUT(invTsS) DC_PUT(invTg) DC_PUT(Qgmin)
+    DC_PUT(inv_dg) DC_PUT(beta) DC_PUT(fA) DC_PUT(fS) DC_PUT(qin) DC_PUT(omb) DC_PUT(cQ) DC_PUT(bQ) DC_PUT(kM) DC_PUT(Esum)
+    DC_PUT(MsusUS) DC_PUT(tA) DC_PUT(tS) DC_PUT(tg) DC_PUT(tconst) DC_PUT(cPP) DC_PUT(PPrUS) DC_PUT(invKv)
+#undef DC_PUT
+}
+struct SysAugLds {
+    typedef double real;
+    typedef DayConstLds dayconst;
+    static constexpr int NS = 11;
+    static constexpr int RESYNC_EVERY = 8;
+    static constexpr int N_ERR = 7;
+    static constexpr bool QUAD_IN_NORM = false;
+    static __device__ __forceinline__ void resync(double (&z)[11], const DayConstLds& c)
+    {
+        const double lq = sp_log(z[3]);
+        sp_exp2(c(DC_bQ) * lq, c(DC_kM) * lq, z[9], z[10]);
+    }
+    static __device__ __forceinline__ void f(const double (&z)[11], const DayConstLds& c, double (&dz)[11], double (&q)[4])
+    {
+        const double fc = c(DC_fc), inv_d = c(DC_inv_d);
+        const double uA = z[0] - fc, uS = z[1] - fc;
+        const double QsA = uA * gate(uA, inv_d) * c(DC_invTsA);
+        const double QsS = uS * gate(uS, inv_d) * c(DC_invTsS);
+        const double aE = c(DC_aE), c0 = c(DC_c0);
+        dz[0] = __builtin_fma(aE, z[7] - 1.0, c0) - QsA;
+        dz[1] = __builtin_fma(aE, z[8] - 1.0, c0) - QsS;
+        const double Qsum = __builtin_fma(c(DC_fA), QsA, c(DC_fS) * QsS);
+        const double Qgmin = c(DC_Qgmin);
+        const double ug = __builtin_fma(z[2], c(DC_invTg), -Qgmin);
+        const double Qg = __builtin_fma(gate(ug, c(DC_inv_dg)), ug, Qgmin);
+        dz[2] = __builtin_fma(c(DC_beta), Qsum, -Qg);
+        const double Qr = z[3], pb = z[9], pk = z[10];
+        const double inflow = __builtin_fma(c(DC_omb), Qsum, c(DC_qin)) + Qg - Qr;
+        const double dQr = inflow * c(DC_cQ) * pb;
+        dz[3] = dQr;
+        const double kap = pb * c(DC_invKv);
+        const double oM = z[4] * kap, oT = z[5] * kap, oP = z[6] * kap;
+        dz[4] = __builtin_fma(c(DC_Esum), pk, c(DC_MsusUS)) - oM;
+        dz[5] = __builtin_fma(c(DC_tA), QsA, __builtin_fma(c(DC_tS), QsS, __builtin_fma(c(DC_tg), Qg, c(DC_tconst)))) - oT;
+        dz[6] = __builtin_fma(c(DC_cPP), pk, c(DC_PPrUS)) - oP;
+        const double mu = c(DC_mu);
+        dz[7] = -mu * z[7] * dz[0];
+        dz[8] = -mu * z[8] * dz[1];
+        const double r = dQr * sp_rcp1(Qr);
+        dz[9] = c(DC_bQ) * pb * r;
+        dz[10] = c(DC_kM) * pk * r;
+        q[0] = Qr; q[1] = oM; q[2] = oT; q[3] = oP;
+    }
+};
+#endif
+
 // fp32 working precision for the augmented system (SIMPLYP_INTEG_CASHKARP_AUG_F32, BASELINE config C5): the 11 stage
 // states and all stage arithmetic in float (half the registers, twice the VALU rate once two waves share a SIMD);
 // the four daily integrals are accumulated in fp64, and everything outside the day's integration -- the carried
@@ -660,6 +726,9 @@ constexpr int CKPT_N = 16;    // y[8], Plab_A, TDPs_A, Plab_NC, TDPs_NC, conc_A,
 
 template <int INTEG, bool SNOW>
 __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, double* s_E, double* s_T, int* s_doy,
+#ifdef SIMPLYP_EXP_LDS_DAYCONST
+                                         double* s_dc,
+#endif
                                          const int lane, const int slot_raw, const int* reaches, const int n_reaches,
                                          const int d_begin, const int d_end, double* ckpt)
 {
@@ -909,7 +978,13 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     const double lq0 = sp_log(y[4]);
                     sp_exp2(b_Q * lq0, k_M * lq0, z[9], z[10]);
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
+#ifdef SIMPLYP_EXP_LDS_DAYCONST
+                    store_dayconst(s_dc, lane, c);
+                    const DayConstLds cl = {(lds_cvd_ptr)(s_dc + lane)};
+                    ck_day<SysAugLds>(z, yq, cl, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
+#else
                     ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
+#endif
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
@@ -1010,13 +1085,24 @@ __device__ __forceinline__ int slot_of_lane(const KernelArgs& a, int group, int 
 }
 
 // fp64 schemes need ~500 registers for the Cash-Karp stages (one wave per SIMD); the fp32 scheme is asked to fit two
+#ifdef SIMPLYP_EXP_LDS_DAYCONST
+#define SIMPLYP_WAVES_PER_SIMD 2
+#define SIMPLYP_DC_DECL __shared__ double s_dc[DC_N * WAVE];
+#define SIMPLYP_DC_ARG s_dc,
+#else
+#define SIMPLYP_WAVES_PER_SIMD 1
+#define SIMPLYP_DC_DECL
+#define SIMPLYP_DC_ARG
+#endif
+
 template <int INTEG, bool SNOW>
-__global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs a)
+__global__ __launch_bounds__(WAVE, SIMPLYP_WAVES_PER_SIMD) void simplyp_chain_kernel(const KernelArgs a)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
     __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
+    SIMPLYP_DC_DECL
     const int c0 = a.chain_ptr[blockIdx.y], c1 = a.chain_ptr[blockIdx.y + 1];
     if (a.win_stride > 0) {      // pilot windows: the same short run over different stretches of the forcing
         KernelArgs w = a;
@@ -1025,10 +1111,10 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs
         w.doy = a.doy ? a.doy + off : nullptr;
         w.member_rhs = a.member_rhs + (size_t)blockIdx.z * a.E;
         w.route = a.route ? a.route + (size_t)blockIdx.z * a.win_route_stride : nullptr;
-        run_slot<INTEG, SNOW>(w, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+        run_slot<INTEG, SNOW>(w, s_P, s_E, s_T, s_doy, SIMPLYP_DC_ARG threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
         return;
     }
-    run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+    run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, SIMPLYP_DC_ARG threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1097,12 +1183,13 @@ __device__ __forceinline__ unsigned queue_take_ticket(const QueueArgs& q, int la
 // The persistent loop has a single exit, at its head, on a scalar: with `break`s in the body hipcc (ROCm 7.2)
 // structurised the ticket loop into a lane-masked inner loop that re-ran task 0 forever.
 template <int INTEG, bool SNOW>
-__global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
+__global__ __launch_bounds__(WAVE, SIMPLYP_WAVES_PER_SIMD) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
     __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
+    SIMPLYP_DC_DECL
     const int lane = threadIdx.x;
     const unsigned G = (unsigned)q.n_groups;
     const unsigned n_tasks = (unsigned)q.n_pairs * G;
@@ -1123,7 +1210,7 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int d_begin = c * q.chunk_days;
             const int d_end = min(a.D, d_begin + q.chunk_days);
-            run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
+            run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, SIMPLYP_DC_ARG lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
                             q.ckpt + (size_t)s * CKPT_N * (size_t)a.E);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

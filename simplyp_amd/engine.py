@@ -155,6 +155,33 @@ class _PinnedBlock(object):
             pass
 
 
+def bind_host_thread_to_gpu_numa_node(device=0):
+    """Best effort: pin the calling thread (and what it allocates next: page-locked buffers are placed by first touch) to
+    the CPUs of the NUMA node the GPU hangs off, so that a rank's 44 GB staging buffer and its PCIe link are on the same
+    socket when 8 ranks stream at once.  Returns the node number or None (no sysfs entry, single-node machine, no
+    permission): never raises."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device)
+        bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open('/sys/bus/pci/devices/%s/numa_node' % bdf) as fh:
+            node = int(fh.read().strip())
+        if node < 0:
+            return None
+        with open('/sys/devices/system/node/node%d/cpulist' % node) as fh:
+            cpus = set()
+            for part in fh.read().strip().split(','):
+                lo, _, hi = part.partition('-')
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None
+
+
 def pinned_empty(shape, dtype=np.float64):
     """numpy array in page-locked host memory (simplyp_host_alloc = hipHostMalloc): what the marshalling code fills and
     what ``Engine.run(..., host_out=...)`` streams the output table into, so that both directions move at PCIe speed

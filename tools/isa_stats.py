@@ -41,7 +41,7 @@ for i, l in enumerate(body):
         if t in labels and labels[t] < i: loops.append((labels[t], i))
 def instrs(a, b): return [l.strip().split()[0] for l in body[a:b + 1] if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
 # the attempt loop: the largest loop that holds the step-size controller's v_log_f32 and touches no global memory
-big = [(a, b) for a, b in loops if 'v_log_f32_e32' in instrs(a, b) and not any(x.startswith(('global_', 'buffer_', 'scratch_', 'flat_')) for x in instrs(a, b))]
+big = [(a, b) for a, b in loops if 'v_log_f32_e32' in instrs(a, b) and not any(x.startswith(('global_', 'buffer_', 'flat_')) for x in instrs(a, b))]
 a, b = max(big, key=lambda ab: len(instrs(*ab)))
 ins = instrs(a, b)
 c = collections.Counter(ins)
@@ -72,5 +72,6 @@ for n, cb in blk:
     br = [x.split()[-1] for x in cb if x.startswith(('s_cbranch', 's_branch'))]
     print('  %-12s %4d instr  fp64 %3d  cndmask %3d  mov %3d  scalar %3d  -> %s' % (
         n[:12], len(cb), sum(v for k, v in cc.items() if 'f64' in k and not k.startswith('v_cmp')), sum(v for k, v in cc.items() if 'cndmask' in k),
-        sum(v for k, v in cc.items() if k.startswith(('v_mov', 'v_accvgpr'))), sum(v for k, v in cc.items() if k.startswith('s_')), ' '.join(br)))
+        sum(v for k, v in cc.items() if k.startswith(('v_mov', 'v_accvgpr'))), sum(v for k, v in cc.items() if k.startswith('s_')), ' '.join(br))
+          + ('  scratch %d ds %d' % (sum(v for k, v in cc.items() if k.startswith('scratch_')), sum(v for k, v in cc.items() if k.startswith('ds_')))))
 print('scratch dir', d)
