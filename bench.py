@@ -130,6 +130,7 @@ def build_problem(cfg, n_members, seed_offset, args):
 
 def main():
     args = parse_args()
+    t_start = time.perf_counter()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
 
@@ -206,7 +207,12 @@ def main():
         return eng.run(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=forcing_of_member,
                        out_reaches=out_reaches, out=out, period_of_day=pod, host_out=host)
 
+    def progress(msg):          # long configurations (c4: ~90 s per pass) must show signs of life on stderr
+        if rank == 0:
+            print("[bench %s] %s (%.0f s)" % (args.config, msg, time.perf_counter() - t_start), file=sys.stderr, flush=True)
+
     def one_step(host):
+        progress("pass: %s" % ("streamed to host" if host is not None else "device-resident"))
         return ensemble.run_sharded(run_fn, dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], opts,
                                     out_reaches=prob['out_reaches'], sharded_inputs=(args.scaling == 'weak'),
                                     total_members=e_total if args.scaling == 'weak' else None, host=host)
@@ -265,7 +271,8 @@ def main():
                 traffic = ent.get('hbm_bytes_per_launch')
             else:
                 traffic_note = "profiles/traffic.json does not describe this build/shape (kernel_source_hash %s): null" % khash
-        waves = (e_local + 63) // 64
+        lanes = int(stats.get('lanes_per_wave', 64) or 64)
+        waves = (e_local + lanes - 1) // lanes
         line = {
             "metric": "catchment-days/sec (ensemble x reaches x days)", "value": value, "unit": "catchment-days/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
@@ -288,7 +295,9 @@ def main():
                          "streamed_chunks": int(step_stats[-1]['streamed_chunks']),
                          "d2h_gbs_over_run": None if host_out is None else out_bytes / (float(np.mean([s['wall_ms'] for s in step_stats])) * 1e-3) / 1e9,
                          "pcie_spec_gbs": PCIE_SPEC_GBS, "host_numa_node": numa_node, "note": stream_note},
-            "occupancy": {"waves_per_gpu": waves, "simd_slots": 1024, "rounds": waves / 1024.0},
+            "occupancy": {"members_per_wave": lanes, "waves_per_gpu": waves, "simd_slots": 1024, "rounds": waves / 1024.0,
+                          "note": "rounds < 1: the ensemble cannot fill the chip; the pass then takes as long as its slowest wave, "
+                                  "i.e. one member's whole daily series (the latency floor, DESIGN.md section 4)" if waves < 1024 and S == 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "simplyp_%s_kernel<%d, false>" % ("queue" if stats.get('queued') else "chain", opts.integrator),
@@ -306,8 +315,10 @@ def main():
             "members_flagged": n_bad,
         }
         if not args.no_parity:
+            progress("parity sample against the CPU oracle")
             line["parity"] = parity(args, eng, prob, opts, out, host_out, stats, e_local)
         if not args.no_cpu_baseline and world == 1:
+            progress("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(prob, D, S)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -327,6 +327,24 @@ int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
                 const double* f_tdp, const double* reach_params,
                 const double* obs, double* gof, simplyp_gof_info* info);
 
+/*
+ * simplyp_gof_spearman -- Spearman's r (visualise_results.py:444-445: DataFrame.corr(method='spearman'), the Pearson
+ * correlation of the average ranks of the paired observed and simulated values) of every member, the one column of the
+ * reference's table that simplyp_gof does not produce.  A rank statistic: each member's simulated values on the
+ * observation days are ranked among themselves by counting (n^2 compares per member and variable, n <= a few thousand),
+ * so this pass costs ~0.1-0.2 s for a 100 000-member table where simplyp_gof costs milliseconds -- call it when wanted.
+ * Arguments as for simplyp_gof;
+ *   rho   device  [SIMPLYP_N_GOF_VARS][n_out_reaches][E], member order; NaN for variables with 10 or fewer observations and
+ *                 for members with a NaN simulated value on an observation day (the reference would rank the remaining
+ *                 pairs; such members carry SIMPLYP_STATUS_NONFINITE anyway)
+ *   info  kernel_ms = all passes; bytes_read = rows of the compact value table streamed in the counting pass
+ */
+int simplyp_gof_spearman(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                         const int32_t* out_reaches, int32_t n_out_reaches,
+                         const double* out, const int32_t* member_of_slot,
+                         const double* f_tdp, const double* reach_params,
+                         const double* obs, double* rho, simplyp_gof_info* info);
+
 /* ---- receiving waterbody: the reference's sum_to_waterbody (model.py:851-900) for a whole ensemble -------------------- */
 enum {  /* columns of the reference's df_summed, in its order: the four summed series (vars_to_sum, :866), the three
            volume-weighted concentrations (:886-888), derived_P_species (:842-845) */

@@ -1206,6 +1206,112 @@ int simplyp_gof(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
     SIMPLYP_GUARD(ctx, gof_impl(ctx, dims, out_mask, out_reaches, n_out_reaches, out, member_of_slot, f_tdp, reach_params, obs, gof, info))
 }
 
+// Spearman's r per member, variable and output reach (the one column of the reference's table that simplyp_gof leaves out).
+static int spearman_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                         const int32_t* out_reaches, int32_t n_out_reaches,
+                         const double* out, const int32_t* member_of_slot,
+                         const double* f_tdp, const double* reach_params,
+                         const double* obs, double* rho, simplyp_gof_info* info)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is pending on this context; call simplyp_sync first");
+    if (!dims || dims->E <= 0 || dims->S <= 0 || dims->D <= 0) return fail(ctx, SIMPLYP_ERR_ARG, "bad dims");
+    if (!out || !f_tdp || !reach_params || !obs || !rho) return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
+    const int want[4] = {SIMPLYP_OUT_QR, SIMPLYP_OUT_MSUS_FLUX, SIMPLYP_OUT_TDP_FLUX, SIMPLYP_OUT_PP_FLUX};
+    const uint32_t need = (1u << want[0]) | (1u << want[1]) | (1u << want[2]) | (1u << want[3]);
+    if ((out_mask & need) != need || (out_mask & ~SIMPLYP_MASK_ALL) != 0u)
+        return fail(ctx, SIMPLYP_ERR_ARG, "out_mask must contain Qr, Msus_kg/day, TDP_kg/day and PP_kg/day");
+    const int E = dims->E, S = dims->S, D = dims->D;
+    const int R = out_reaches ? n_out_reaches : S;
+    if (R <= 0 || R > S) return fail(ctx, SIMPLYP_ERR_ARG, "bad n_out_reaches");
+    for (int r = 0; r < R; ++r)
+        if (out_reaches && (out_reaches[r] < 0 || out_reaches[r] >= S)) return fail(ctx, SIMPLYP_ERR_ARG, "out_reaches[%d] out of range", r);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    constexpr int NV = SIMPLYP_N_GOF_VARS;
+    {   // variables without (enough) observations stay NaN (visualise_results.py:430, :453)
+        std::vector<double> nanv((size_t)NV * R * E, std::nan(""));
+        HIP_TRY(ctx, hipMemcpyAsync(rho, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    simplyp::SpearmanArgs g{};
+    for (int i = 0; i < 4; ++i) g.col[i] = popcount32(out_mask & ((1u << want[i]) - 1u));
+    g.E = E; g.R = R; g.D = D;
+    g.out = out; g.col_stride = (long long)D * R * E;
+    g.member_of_slot = member_of_slot; g.f_tdp = f_tdp; g.rho = rho;
+    const int groups = (E + simplyp::WAVE - 1) / simplyp::WAVE;
+    double ms_total = 0.0;
+    long long pairs = 0;
+    int n_q = 0, n_c = 0;
+    for (int r = 0; r < R; ++r) {
+        const int reach = out_reaches ? out_reaches[r] : r;
+        for (int v = 0; v < NV; ++v) {
+            const double* ob = obs + ((size_t)r * NV + v) * D;
+            std::vector<int32_t> day;
+            std::vector<double> val;
+            for (int d = 0; d < D; ++d) if (ob[d] == ob[d]) { day.push_back(d); val.push_back(ob[d]); }
+            const int n = (int)day.size();
+            if (n <= 10) continue;                                                    // :430
+            // average ranks of the observations (ties share the mean of their positions, like pandas' rank())
+            std::vector<int> idx((size_t)n);
+            std::iota(idx.begin(), idx.end(), 0);
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return val[a] < val[b]; });
+            std::vector<double> rk((size_t)n);
+            double sum_ro = 0.0, sum_ro2 = 0.0;
+            for (int i = 0; i < n;) {
+                int j = i;
+                while (j + 1 < n && val[idx[j + 1]] == val[idx[i]]) ++j;
+                const double avg = 0.5 * ((double)(i + 1) + (double)(j + 1));
+                for (int k = i; k <= j; ++k) rk[idx[k]] = avg;
+                i = j + 1;
+            }
+            for (int i = 0; i < n; ++i) { sum_ro += rk[i]; sum_ro2 += rk[i] * rk[i]; }
+            const int n_blocks = (n + simplyp::SP_TI - 1) / simplyp::SP_TI;
+            const size_t list_bytes = ((size_t)n * sizeof(int32_t) + 7) / 8 * 8;
+            if (int rc = ensure(ctx, ctx->gof_lists, list_bytes + (size_t)n * sizeof(double))) return rc;
+            if (int rc = ensure(ctx, ctx->gof_partial, ((size_t)n + (size_t)n_blocks * 3) * E * sizeof(double))) return rc;
+            char* base = (char*)ctx->gof_lists.ptr;
+            HIP_TRY(ctx, hipMemcpyAsync(base, day.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(base + list_bytes, rk.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));        // the host vectors go out of scope at the end of this iteration
+            g.n = n; g.var = v; g.r = r;
+            g.a_catch = reach_params + ((size_t)SIMPLYP_PR_A_CATCH * S + reach) * E;
+            g.day = (const int32_t*)base; g.rank_obs = (const double*)(base + list_bytes);
+            g.sum_ro = sum_ro; g.sum_ro2 = sum_ro2;
+            g.vals = (double*)ctx->gof_partial.ptr; g.partial = g.vals + (size_t)n * E; g.n_blocks = n_blocks;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+            hipLaunchKernelGGL(simplyp::simplyp_spearman_fill_kernel, dim3(groups, (unsigned)std::min(n, 64)), dim3(simplyp::WAVE), 0, ctx->stream, g);
+            HIP_TRY(ctx, hipGetLastError());
+            hipLaunchKernelGGL(simplyp::simplyp_spearman_count_kernel, dim3(groups, (unsigned)n_blocks), dim3(simplyp::WAVE), 0, ctx->stream, g);
+            HIP_TRY(ctx, hipGetLastError());
+            hipLaunchKernelGGL(simplyp::simplyp_spearman_finish_kernel, dim3(groups), dim3(simplyp::WAVE), 0, ctx->stream, g);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+            ms_total += ms;
+            pairs += (long long)n * n;
+            if (v == SIMPLYP_GOF_Q) n_q += n; else n_c += n;
+        }
+    }
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->kernel_ms = ms_total;
+        info->n_q_days = n_q; info->n_chem_days = n_c;
+        info->bytes_read = pairs / simplyp::SP_TI * 8 * E;       // rows of the compact table streamed past each block of SP_TI values
+    }
+    return SIMPLYP_OK;
+}
+
+int simplyp_gof_spearman(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mask,
+                         const int32_t* out_reaches, int32_t n_out_reaches,
+                         const double* out, const int32_t* member_of_slot,
+                         const double* f_tdp, const double* reach_params,
+                         const double* obs, double* rho, simplyp_gof_info* info)
+{
+    SIMPLYP_GUARD(ctx, spearman_impl(ctx, dims, out_mask, out_reaches, n_out_reaches, out, member_of_slot, f_tdp, reach_params, obs, rho, info))
+}
+
 int simplyp_gof_waterbody(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t wb_mask, const double* wb,
                           const int32_t* member_of_slot, const double* f_tdp,
                           const double* obs, double* gof, simplyp_gof_info* info)

@@ -26,7 +26,7 @@ ABI_SYMBOLS = ['simplyp_abi_version', 'simplyp_device_count', 'simplyp_ctx_creat
                'simplyp_last_error', 'simplyp_ctx_set_stream', 'simplyp_out_bytes', 'simplyp_run',
                'simplyp_run_async', 'simplyp_sync', 'simplyp_plan', 'simplyp_host_alloc', 'simplyp_host_free',
                'simplyp_device_alloc', 'simplyp_device_free', 'simplyp_memcpy_h2d', 'simplyp_memcpy_d2h', 'simplyp_gof',
-               'simplyp_stream_out', 'simplyp_waterbody', 'simplyp_gof_waterbody']
+               'simplyp_stream_out', 'simplyp_waterbody', 'simplyp_gof_waterbody', 'simplyp_gof_spearman']
 
 _lib = None
 
@@ -90,6 +90,8 @@ def lib():
     L.simplyp_gof.restype = C.c_int
     L.simplyp_gof.argtypes = [vp, C.POINTER(abi.Dims), C.c_uint32, C.POINTER(C.c_int32), C.c_int32, dp, i32p, dp, dp,
                               C.POINTER(C.c_double), dp, C.POINTER(abi.GofInfo)]
+    L.simplyp_gof_spearman.restype = C.c_int
+    L.simplyp_gof_spearman.argtypes = L.simplyp_gof.argtypes
     L.simplyp_waterbody.restype = C.c_int
     L.simplyp_waterbody.argtypes = [vp, C.POINTER(abi.Dims), C.c_uint32, C.POINTER(C.c_int32), C.c_int32, dp, i32p, dp, dp,
                                     C.POINTER(C.c_int32), C.c_int32, C.c_uint32, dp, C.POINTER(abi.WbInfo)]
@@ -336,14 +338,16 @@ class Engine(object):
         return out, status, sd
 
 
-    def gof(self, out, out_mask, obs, f_tdp, reach_params, out_reaches=None, member_of_slot=None):
+    def gof(self, out, out_mask, obs, f_tdp, reach_params, out_reaches=None, member_of_slot=None, spearman=False):
         """Per-member goodness-of-fit statistics (the reference's ``goodness_of_fit_stats``,
         visualise_results.py:387-474, without Spearman's r) of the daily table ``out`` of a previous ``run``.
 
         out [n_cols,D,n_out_reaches,E] device tensor written with ``out_mask`` (must contain Qr and the three daily
         fluxes); obs [n_out_reaches,6,D] host array, NaN = no observation (``visualise_results.observation_array``);
         f_tdp [E] or scalar; reach_params [NP_R,S,E].  Returns (gof [n_stats,6,n_out_reaches,E] device tensor in member
-        order -- rows ``abi.GOF_STATS``, variables ``abi.GOF_VARS`` -- and an info dict)."""
+        order -- rows ``abi.GOF_STATS``, variables ``abi.GOF_VARS`` -- and an info dict).  ``spearman=True`` adds the rank
+        correlation (``simplyp_gof_spearman``, the remaining column of the reference's table) as
+        ``info['spearman']`` [6, n_out_reaches, E] device tensor and its cost as ``info['spearman_ms']``."""
         torch = self.torch
         L = lib()
         rp = self.to_device(reach_params, torch.float64)
@@ -371,7 +375,20 @@ class Engine(object):
                                ft.data_ptr(), rp.data_ptr(), obs.ctypes.data_as(C.POINTER(C.c_double)), gof.data_ptr(),
                                C.byref(info))
         self._check(rc, 'simplyp_gof')
-        return gof, info.as_dict()
+        d = info.as_dict()
+        if spearman:
+            rho = torch.empty((len(abi.GOF_VARS), n_or, E), dtype=torch.float64, device=self.tdev)
+            sinfo = abi.GofInfo()
+            with torch.cuda.device(self.tdev):
+                rc = L.simplyp_gof_spearman(self._h, C.byref(dims), int(out_mask),
+                                            None if oreach is None else oreach.ctypes.data_as(C.POINTER(C.c_int32)), n_or,
+                                            out.data_ptr(), None if member_of_slot is None else member_of_slot.data_ptr(),
+                                            ft.data_ptr(), rp.data_ptr(), obs.ctypes.data_as(C.POINTER(C.c_double)),
+                                            rho.data_ptr(), C.byref(sinfo))
+            self._check(rc, 'simplyp_gof_spearman')
+            d['spearman'] = rho
+            d['spearman_ms'] = sinfo.kernel_ms
+        return gof, d
 
 
     def _f_tdp(self, f_tdp, E):

@@ -231,7 +231,7 @@ def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len
 def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
                           outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True,
                           reduce=None, obs_dict=None, keep_daily=True, snow_in_kernel=None, forcing_of_member=None,
-                          waterbody=None, waterbody_obs=None):
+                          waterbody=None, waterbody_obs=None, spearman=False):
     """Run an ensemble of parameter sets through the engine in one call.
 
     ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
@@ -251,7 +251,8 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     visualise_results.py:387-474, minus Spearman's r, plus the two sums of its Gaussian likelihood) is reduced on the
     device from the daily series and returned under ``'gof'`` = dict(stats, variables, data[n_stats, 6, n_reaches, E],
     info); needs daily rows (``reduce=None``); the four flux columns are added to ``outputs`` when missing.  ``SRP``
-    uses ``p['f_TDP']`` or ``overrides['f_TDP']`` (array[E]).  ``keep_daily=False`` drops the daily table once the
+    uses ``p['f_TDP']`` or ``overrides['f_TDP']`` (array[E]).  ``spearman=True`` adds the table's rank statistic under
+    ``['gof']['spearman']`` [6, n_reaches, E] (counted on the device, ~0.1-0.2 s for 100 000 members).  ``keep_daily=False`` drops the daily table once the
     statistics exist (``data`` is None): the 44 GB of a 100 000-member run never leave the device.
 
     ``waterbody``: the reference's ``sum_to_waterbody`` (model.py:851-900) for every member, on the device: ``True`` sums
@@ -361,9 +362,12 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
         from . import visualise_results as vr
         obs = vr.observation_array(obs_dict, reaches, met_df.index)
         gof_d, info = eng.gof(out_d, mask, obs, p['f_TDP'] if f_tdp is None else f_tdp, rp_d, out_reaches=oreach,
-                              member_of_slot=stats.get('member_of_slot') if opts.out_slot_order else None)
+                              member_of_slot=stats.get('member_of_slot') if opts.out_slot_order else None, spearman=spearman)
+        rho = info.pop('spearman', None)
         res['gof'] = dict(stats=list(abi.GOF_STATS), variables=list(abi.GOF_VARS), info=info,
                           data=gof_d.cpu().numpy() if to_host else gof_d)
+        if rho is not None:       # Spearman's r [6, n_reaches, E]: the rank statistic of the reference's table (:444-445)
+            res['gof']['spearman'] = rho.cpu().numpy() if to_host else rho
     if wb_reaches is not None:
         if len(wb_reaches) > 1:
             mos = stats.get('member_of_slot') if opts.out_slot_order else None

@@ -160,3 +160,66 @@ def test_run_simply_p_ensemble_with_observations(engine0):
     assert np.array_equal(np.delete(g[:, :, 3], srp, axis=1), np.delete(g[:, :, 0], srp, axis=1))
     assert not np.allclose(g[1:, srp, 3], g[1:, srp, 0])
     assert not np.allclose(g[1, 0, 1], g[1, 0, 0])            # another fc: another NSE of Q
+
+
+def test_spearman_matches_the_oracle_and_the_reference_table(engine0):
+    """simplyp_gof_spearman (ranks counted on the device) against scipy's rankdata-based restatement of
+    DataFrame.corr(method='spearman') (oracle/gof.py::spearman_of_pair) for a ragged perturbed ensemble: 1e-9; the base
+    member against the 'Spearmans r' column of the table the reference function made from its own tight run: 2e-5
+    (a rank statistic moves only when two simulated values change order)."""
+    name = 'tarland_1981_2010_dynamic'
+    E = 70
+    m, out, status, _ = perturbed_run(engine0, name, E, marshal.MASK_REACH5, solver=dict(rtol=1e-6, atol=1e-8))
+    info = helpers.meta()[name]['inputs']
+    obs = vr.observation_array(helpers.observations(info['p_SU']['st_dt'], info['p_SU']['end_dt']), [1], m['met'].index)
+    f_tdp = np.linspace(0.5, 0.9, E)
+    gof, ginfo = engine0.gof(out, marshal.MASK_REACH5, obs, f_tdp, m['reach_params'], spearman=True)
+    rho = ginfo['spearman'].cpu().numpy()
+    assert rho.shape == (6, 1, E) and ginfo['spearman_ms'] > 0
+    o = out.cpu().numpy()
+    cols = marshal.REACH5_COLUMNS
+    A = m['reach_params'][marshal.PR_NAMES.index('A_catch'), 0]
+    for e in (0, 1, 33, 69):
+        sim = ogof.simulated_series(*[o[cols.index(c), :, 0, e] for c in FLUX], A[e], f_tdp[e])
+        for vi, v in enumerate(abi.GOF_VARS):
+            want = ogof.spearman_of_pair(obs[0, vi], sim[v])
+            assert abs(rho[vi, 0, e] - want) < 1e-9, (e, v, rho[vi, 0, e], want)
+    # base member, parity-grade solver, against the reference's own table
+    b = helpers.marshal_scenario(name, E=2, out_mask=marshal.MASK_REACH5)
+    bo, _, _ = engine0.run(b['forcing'], b['doy'], b['member_params'], b['reach_params'], b['up_ptr'], b['up_idx'], b['opts'])
+    _, binfo = engine0.gof(bo, marshal.MASK_REACH5, obs, info['p']['f_TDP'], b['reach_params'], spearman=True)
+    t = helpers.gof_golden()[name + '/tight/base']
+    gold = pd.DataFrame(t['values'], index=t['index'], columns=t['columns'])
+    got = binfo['spearman'].cpu().numpy()[:, 0, 0]
+    for vi, v in enumerate(abi.GOF_VARS):
+        assert abs(got[vi] - float(gold.loc[v, 'Spearmans r'])) < 2e-5, (v, got[vi], gold.loc[v, 'Spearmans r'])
+
+
+def test_spearman_ties_dropped_variables_slot_order(engine0):
+    """Ties in the simulated series (replicated days) and in the observations get average ranks; a variable with <= 10
+    observations stays NaN; a slot-ordered table comes back in member order."""
+    import torch
+    name = 'tarland_2004_dynamic'
+    E = 130
+    m, out, status, _ = perturbed_run(engine0, name, E, marshal.mask_of_columns(FLUX), solver=dict(balance=1, out_slot_order=1))
+    o = out.clone()
+    o[:, 40:60] = o[:, 39:40]                     # 21 equal days in every simulated series
+    rng = np.random.default_rng(4)
+    D = o.shape[1]
+    obs = np.full((1, 6, D), np.nan)
+    obs[0, 0, 10:200] = np.round(rng.uniform(0.2, 3.0, 190), 1)      # many tied observations
+    obs[0, 2, ::9] = rng.uniform(0.01, 0.1, len(range(0, D, 9)))
+    obs[0, 5, :8] = 0.02                                             # 8 observations: dropped
+    st = engine0.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])[2]
+    mos = st['member_of_slot']
+    _, ginfo = engine0.gof(o, marshal.mask_of_columns(FLUX), obs, 0.7, m['reach_params'], member_of_slot=mos, spearman=True)
+    rho = ginfo['spearman'].cpu().numpy()[:, 0, :]
+    assert np.isnan(rho[[1, 3, 4, 5]]).all()
+    on = o.cpu().numpy()
+    slot_of = np.empty(E, dtype=np.int64); slot_of[mos.cpu().numpy()] = np.arange(E)
+    A = m['reach_params'][marshal.PR_NAMES.index('A_catch'), 0]
+    for e in (0, 7, 129):
+        sim = ogof.simulated_series(*[on[i, :, 0, slot_of[e]] for i in range(4)], A[e], 0.7)
+        for vi in (0, 2):
+            want = ogof.spearman_of_pair(obs[0, vi], sim[abi.GOF_VARS[vi]])
+            assert abs(rho[vi, e] - want) < 1e-9, (e, vi, rho[vi, e], want)
