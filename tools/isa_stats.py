@@ -74,4 +74,27 @@ for n, cb in blk:
         n[:12], len(cb), sum(v for k, v in cc.items() if 'f64' in k and not k.startswith('v_cmp')), sum(v for k, v in cc.items() if 'cndmask' in k),
         sum(v for k, v in cc.items() if k.startswith(('v_mov', 'v_accvgpr'))), sum(v for k, v in cc.items() if k.startswith('s_')), ' '.join(br))
           + ('  scratch %d ds %d' % (sum(v for k, v in cc.items() if k.startswith('scratch_')), sum(v for k, v in cc.items() if k.startswith('ds_')))))
+# back-to-back dependencies in the biggest block (a lone wave cannot hide the latency of a dependent fp64 instruction: each one
+# that reads the result of the instruction right before it stalls the issue by about one more slot)
+def vregs(tok):
+    m = re.match(r'v\[(\d+):(\d+)\]', tok)
+    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'v(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+main = max(blk, key=lambda nb: len(nb[1]))[1]
+prev, n_valu, dep1, dep2 = [], 0, 0, 0
+for ins in main:
+    parts = ins.replace(',', ' ').split()
+    if not parts[0].startswith('v_'):
+        prev.append(set()); continue
+    toks = [re.sub(r'^(neg|abs)\(|\)$', '', t.strip('|-')) for t in parts[1:]]
+    dst = vregs(toks[0]) if toks else set()
+    srcs = set()
+    for t in toks[1:]: srcs |= vregs(t)
+    if parts[0].startswith('v_fmac'): srcs |= dst
+    n_valu += 1
+    if prev and prev[-1] & srcs: dep1 += 1
+    elif len(prev) > 1 and prev[-2] & srcs: dep2 += 1
+    prev.append(dst)
+print('main block: %d VALU, %d read the previous instruction\'s result, %d the one before' % (n_valu, dep1, dep2))
 print('scratch dir', d)
