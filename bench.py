@@ -94,6 +94,17 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def host_mem_available():
+    try:
+        with open('/proc/meminfo') as fh:
+            for line in fh:
+                if line.startswith('MemAvailable:'):
+                    return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return None
+
+
 def kernel_source_hash():
     """sha256 over the sources the kernels are built from: profiles/traffic.json is only valid for the build it was
     measured on."""
@@ -198,10 +209,18 @@ def main():
     host_out = None
     stream_note = None
     if not args.no_stream:
-        try:
-            host_out = engine.pinned_empty((ncols, rows, n_or, e_local), np.float64)
-        except engine.EngineError as ex:          # not enough lockable host memory on this node
-            stream_note = "pinned host buffer of %.1f GB not available (%s): table left in HBM" % (out_bytes / 1e9, ex)
+        # every rank of the node page-locks its own copy of its table: refuse up front when that would take more than 60 % of
+        # what the host has available (a node that starts swapping or OOM-kills a rank measures nothing)
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+        avail = host_mem_available()
+        if avail is not None and out_bytes * local_world > 0.6 * avail:
+            stream_note = ("%d ranks x %.1f GB of pinned staging exceed 60 %% of the host's available memory (%.0f GB): table left "
+                           "in HBM" % (local_world, out_bytes / 1e9, avail / 1e9))
+        else:
+            try:
+                host_out = engine.pinned_empty((ncols, rows, n_or, e_local), np.float64)
+            except engine.EngineError as ex:          # not enough lockable host memory on this node
+                stream_note = "pinned host buffer of %.1f GB not available (%s): table left in HBM" % (out_bytes / 1e9, ex)
 
     def run_fn(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=None, out_reaches=None, host=None):
         return eng.run(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=forcing_of_member,
