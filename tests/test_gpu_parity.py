@@ -614,11 +614,12 @@ def test_fp32_stage_mode_against_its_oracle_mirror(engine0, oracle_lib, name):
 def test_random_reach_networks_match_the_oracle(engine0, oracle_lib, seed):
     """Random upstream graphs (12 reaches; 0-2 upstream reaches each, a reach may feed several downstream reaches; reaches
     with newly-converted land of either kind, blank TDPeff, varied areas / lengths / slopes), 40 perturbed members,
-    120 days: chain kernel and pipelined task queue against the CPU oracle (routing of same-day means and fluxes,
-    model.py:508-544) -- 1e-10 with RK4, 10 x rtol with the default solver -- and bit-identical to each other."""
+    one year: chain kernel and pipelined task queue against the CPU oracle (routing of same-day means and fluxes,
+    model.py:508-544) -- 1e-9 with RK4 (rounding only: the kernel's hoisted day constants against the oracle's literal
+    formulas, carried through up to 7 reaches in series; measured 1.9e-10), 10 x rtol with the default solver -- and bit-identical to each other."""
     import torch
     rng = np.random.default_rng(100 + seed)
-    S, E, D = 12, 40, 120
+    S, E = 12, 40
     base = helpers.marshal_scenario('confluence3_nc_2004', E=E)
     rp0 = base['reach_params']                                   # [NP_R, 3, E]
     rp = np.empty((marshal.NP_R, S, E))
@@ -638,9 +639,8 @@ def test_random_reach_networks_match_the_oracle(engine0, oracle_lib, seed):
     mp = base['member_params'].copy()
     for pname, lo, hi in (('fc', 0.9, 1.1), ('T_g', 0.7, 1.4), ('a_Q', 0.7, 1.5), ('E_M', 0.5, 2.0)):
         mp[marshal.PM_NAMES.index(pname)] *= rng.uniform(lo, hi, E)
-    m = dict(base, forcing=np.ascontiguousarray(base['forcing'][:, :, 100:100 + D]), doy=np.ascontiguousarray(base['doy'][100:100 + D]),
-             member_params=mp, reach_params=rp, up_ptr=np.asarray(up_ptr, dtype=np.int32), up_idx=np.asarray(up_idx, dtype=np.int32))
-    for solver, tol in ((dict(integrator='rk4', substeps=24), 1e-10), (None, 1e-7)):
+    m = dict(base, member_params=mp, reach_params=rp, up_ptr=np.asarray(up_ptr, dtype=np.int32), up_idx=np.asarray(up_idx, dtype=np.int32))
+    for solver, tol in ((dict(integrator='rk4', substeps=96), 1e-9), (None, 1e-7)):      # (24 substeps are unstable on the big confluences)
         m['opts'] = abi.make_opts(solver, dynamic_epc0=True, dynamic_erod=True, run_mode_cal=True, sc_qr0=S - 1, out_mask=marshal.MASK_ALL)
         ref, ref_status, _ = cpu_run(oracle_lib, m, n_threads=8)
         m['opts'].time_chunk_days = -1
@@ -648,7 +648,7 @@ def test_random_reach_networks_match_the_oracle(engine0, oracle_lib, seed):
         assert cst['queued'] == 0 and cs.max() == 0 and ref_status.max() == 0
         assert helpers.max_rel_err(chain, ref, floor=FLOOR) < tol, (seed, solver)
         if solver is None:
-            m['opts'].time_chunk_days = 64
+            m['opts'].time_chunk_days = 256
             queue, qs, qst = gpu_run(engine0, m)
             assert qst['queued'] == 1
             assert np.array_equal(queue, chain, equal_nan=True) and np.array_equal(qs, cs)
