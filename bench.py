@@ -38,6 +38,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64
 PCIE_SPEC_GBS = 63.0             # PCIe Gen5 x16, same guide
+# what the chip actually issues: v_fma_f64 at 4.72 ns per instruction and wave with two waves per SIMD (2.60 ns for a lone wave),
+# tools/micro/valu_rates.hip on MI355X (profiles/r02_valu_rates.log) -> 1024 SIMDs x 128 flops / 2.36 ns
+FP64_FMA_MEASURED_TFLOPS = 1024 * 128 / 2.36e-9 / 1e12
 # fp64 operations of one Cash-Karp attempt of one member on the augmented system (6 right-hand sides + stage sums + error
 # norm + update), counted in the gfx950 ISA of simplyp_queue_kernel<2,false>'s attempt loop (common path): 369 FMAs (x2) +
 # 223 mul + 76 add + 14 max + 13 rcp (Roofline)
@@ -329,6 +332,8 @@ def main():
                           "achieved_tflops": FLOPS_PER_ATTEMPT * (rhs / 6.0) / (k_ms * 1e-3) / 1e12,
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                           "frac": FLOPS_PER_ATTEMPT * (rhs / 6.0) / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                          "measured_fma_issue_tflops": FP64_FMA_MEASURED_TFLOPS,
+                          "frac_of_measured_issue": FLOPS_PER_ATTEMPT * (rhs / 6.0) / (k_ms * 1e-3) / 1e12 / FP64_FMA_MEASURED_TFLOPS,
                           "note": "useful lane-attempts only (lanes idling in a diverged wave are not counted); peak = all-FMA issue"
                                   + ("; flop count is the fp64 kernel's, this config runs fp32 stages" if args.config == 'c5' else "")},
             "members_flagged": n_bad,
