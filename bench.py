@@ -42,9 +42,9 @@ PCIE_SPEC_GBS = 63.0             # PCIe Gen5 x16, same guide
 # tools/micro/valu_rates.hip on MI355X (profiles/r02_valu_rates.log) -> 1024 SIMDs x 128 flops / 2.36 ns
 FP64_FMA_MEASURED_TFLOPS = 1024 * 128 / 2.36e-9 / 1e12
 # fp64 operations of one Cash-Karp attempt of one member on the augmented system (6 right-hand sides + stage sums + error
-# norm + update), counted in the gfx950 ISA of simplyp_queue_kernel<2,false>'s attempt loop (common path): 369 FMAs (x2) +
-# 223 mul + 76 add + 14 max + 13 rcp (Roofline)
-FLOPS_PER_ATTEMPT = 2 * 369 + 223 + 76 + 14 + 13
+# norm + update), counted in the gfx950 ISA of simplyp_queue_kernel<2,false>'s attempt loop (common path, tools/isa_stats.py):
+# 393 FMAs (x2) + 192 mul + 48 add + 14 max + 13 rcp = 660 fp64 instructions (Roofline)
+FLOPS_PER_ATTEMPT = 2 * 393 + 192 + 48 + 14 + 13
 
 # BASELINE.json's configurations.  bytes_per_cd: algorithmic HBM bytes per catchment-day of the
 # config's output mode -- FULL = 25 outputs x 8 B + 2 forcing values x 8 B; REACH-5 = 5 x 8 + 16; annual sums = 16 B of

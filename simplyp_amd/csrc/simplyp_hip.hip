@@ -882,11 +882,7 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
             k.route_slot = dq + off_qslot;
             k.chain_ptr = nullptr; k.chain_reach = nullptr;
             const long long n_tasks = (long long)pair_idx.size() * G;
-#ifdef SIMPLYP_EXP_LDS_DAYCONST
-            unsigned workers = (unsigned)std::min<long long>(n_tasks, 2LL * ctx->n_simd_slots);       // experiment: two resident waves per SIMD
-#else
             unsigned workers = (unsigned)std::min<long long>(n_tasks, ctx->n_simd_slots);
-#endif
             if (const char* w_env = getenv("SIMPLYP_QUEUE_WORKERS")) workers = std::max(1u, std::min(workers, (unsigned)strtoul(w_env, nullptr, 10)));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 #define SIMPLYP_LAUNCH_QUEUE(INTEG)                                                                                                       \

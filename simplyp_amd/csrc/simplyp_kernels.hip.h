@@ -188,6 +188,11 @@ struct DayConst {
     double cPP, PPrUS;
     // augmented form only
     double invKv;       // a_Q 86400 / L_reach = (Qr/Vr) / Qr**b_Q
+    // fused forms used by SysAug::f (one FMA where the literal form has a subtraction and a multiplication)
+    double wA0, wS0;    // -fc / T_s:   (Vs - fc) / T_s = fma(Vs, invTs, w0)
+    double s0;          // -fc inv_d:   (Vs - fc) inv_d = fma(Vs, inv_d, s0)
+    double c0m;         // c0 - aE:     c0 + aE (E - 1) = fma(aE, E, c0m)
+    double invKvc;      // invKv / cQ:  the state carried for Qr**b_Q is cQ Qr**b_Q, so dQr = inflow * state and Qr/Vr = state * invKvc
 };
 
 // f_x(x, threshold, 0.01) with u = x - threshold and inv_d = 1/(0.01 threshold) (model.py:23-37):
@@ -313,27 +318,37 @@ struct SysAug {
     // quadratures of them; see oracle/simplyp_oracle.c)
     static constexpr int N_ERR = 7;
     static constexpr bool QUAD_IN_NORM = false;
+    // z[9] carries cQ * Qr**b_Q (the factor the flow equation multiplies it with, folded into the state: one multiplication
+    // less per right-hand side; its ODE is linear in it, so the scaling changes nothing else)
     static __device__ __forceinline__ void resync(double (&z)[11], const DayConst& c)
     {
         const double lq = sp_log(z[3]);
-        sp_exp2(c.bQ * lq, c.kM * lq, z[9], z[10]);
+        double pb;
+        sp_exp2(c.bQ * lq, c.kM * lq, pb, z[10]);
+        z[9] = c.cQ * pb;
     }
+    // 61 fp64 operations (the literal grouping of the same expressions takes 66): every "(x - a) * b" is one FMA with the
+    // per-day / per-member constant -a*b, and cQ rides inside the auxiliary state.
     static __device__ __forceinline__ void f(const double (&z)[11], const DayConst& c, double (&dz)[11], double (&q)[4])
     {
-        const double uA = z[0] - c.fc, uS = z[1] - c.fc;
-        const double QsA = uA * gate(uA, c.inv_d) * c.invTsA;                         // :105
-        const double QsS = uS * gate(uS, c.inv_d) * c.invTsS;                         // :109
-        dz[0] = __builtin_fma(c.aE, z[7] - 1.0, c.c0) - QsA;                          // :106 with EA = exp(-mu VsA)
-        dz[1] = __builtin_fma(c.aE, z[8] - 1.0, c.c0) - QsS;                          // :110
+        // soil boxes: Qs = (Vs - fc)/T_s * f_x(Vs, fc) with f_x = s^2 (3 - 2 s), s = clamp((Vs - fc) inv_d, 0, 1)   (:105, :109)
+        const double wA = __builtin_fma(z[0], c.invTsA, c.wA0), wS = __builtin_fma(z[1], c.invTsS, c.wS0);
+        double sA = __builtin_fma(z[0], c.inv_d, c.s0), sS = __builtin_fma(z[1], c.inv_d, c.s0);
+        sA = __builtin_fmin(__builtin_fmax(sA, 0.0), 1.0);
+        sS = __builtin_fmin(__builtin_fmax(sS, 0.0), 1.0);
+        const double QsA = wA * ((sA * sA) * __builtin_fma(-2.0, sA, 3.0));
+        const double QsS = wS * ((sS * sS) * __builtin_fma(-2.0, sS, 3.0));
+        dz[0] = __builtin_fma(c.aE, z[7], c.c0m) - QsA;                               // :106 with EA = exp(-mu VsA)
+        dz[1] = __builtin_fma(c.aE, z[8], c.c0m) - QsS;                               // :110
         const double Qsum = __builtin_fma(c.fA, QsA, c.fS * QsS);
         const double ug = __builtin_fma(z[2], c.invTg, -c.Qgmin);
         const double Qg = __builtin_fma(gate(ug, c.inv_dg), ug, c.Qgmin);             // :121-122
         dz[2] = __builtin_fma(c.beta, Qsum, -Qg);                                     // :124
-        const double Qr = z[3], pb = z[9], pk = z[10];
+        const double Qr = z[3], pbc = z[9], pk = z[10];
         const double inflow = __builtin_fma(c.omb, Qsum, c.qin) + Qg - Qr;            // :127-129
-        const double dQr = inflow * c.cQ * pb;                                        // :130
+        const double dQr = inflow * pbc;                                              // :130
         dz[3] = dQr;
-        const double kap = pb * c.invKv;                                              // Qr / Vr on the invariant
+        const double kap = pbc * c.invKvc;                                            // Qr / Vr on the invariant
         const double oM = z[4] * kap, oT = z[5] * kap, oP = z[6] * kap;
         dz[4] = __builtin_fma(c.Esum, pk, c.MsusUS) - oM;                             // :141-145
         dz[5] = __builtin_fma(c.tA, QsA, __builtin_fma(c.tS, QsS, __builtin_fma(c.tg, Qg, c.tconst))) - oT;   // :154-166
@@ -341,78 +356,12 @@ struct SysAug {
         dz[7] = -c.mu * z[7] * dz[0];                                                 // d exp(-mu VsA)
         dz[8] = -c.mu * z[8] * dz[1];
         const double r = dQr * sp_rcp1(Qr);
-        dz[9] = c.bQ * pb * r;                                                        // d Qr**b_Q
+        dz[9] = c.bQ * pbc * r;                                                       // d (cQ Qr**b_Q)
         dz[10] = c.kM * pk * r;                                                       // d Qr**k_M
         q[0] = Qr; q[1] = oM; q[2] = oT; q[3] = oP;                                   // :132,:147,:168,:180
     }
 };
 
-
-#ifdef SIMPLYP_EXP_LDS_DAYCONST
-// EXPERIMENT (tools/build_variant.sh; not in the product build): the 27 day constants live in LDS ([27][64] doubles per wave,
-// 13.8 KB) and the right-hand side reads each one where it is used, so that they do not occupy 54 registers across the attempt
-// loop -- the precondition for fitting two waves per SIMD (<= 256 registers).
-enum { DC_c0, DC_aE, DC_mu, DC_fc, DC_inv_d, DC_invTsA, DC_invTsS, DC_invTg, DC_Qgmin, DC_inv_dg, DC_beta, DC_fA, DC_fS, DC_qin,
-       DC_omb, DC_cQ, DC_bQ, DC_kM, DC_Esum, DC_MsusUS, DC_tA, DC_tS, DC_tg, DC_tconst, DC_cPP, DC_PPrUS, DC_invKv, DC_N };
-typedef const volatile __attribute__((address_space(3))) double* lds_cvd_ptr;
-struct DayConstLds {
-    lds_cvd_ptr p;                  // &s_dc[lane] in the LDS address space (ds_read_b64, not a flat load); constant k at p[k * WAVE]
-    __device__ __forceinline__ double operator()(int k) const { return p[k * WAVE]; }
-};
-__device__ __forceinline__ void store_dayconst(double* s, int lane, const DayConst& c)
-{
-    double* p = s + lane;
-#define DC_PUT(n) p[DC_##n * WAVE] = c.n;
-    DC_PUT(c0) DC_PUT(aE) DC_PUT(mu) DC_PUT(fc) DC_PUT(inv_d) DC_PUT(invTsA) DC_PUT(invTsS) DC_PUT(invTg) DC_PUT(Qgmin)
-    DC_PUT(inv_dg) DC_PUT(beta) DC_PUT(fA) DC_PUT(fS) DC_PUT(qin) DC_PUT(omb) DC_PUT(cQ) DC_PUT(bQ) DC_PUT(kM) DC_PUT(Esum)
-    DC_PUT(MsusUS) DC_PUT(tA) DC_PUT(tS) DC_PUT(tg) DC_PUT(tconst) DC_PUT(cPP) DC_PUT(PPrUS) DC_PUT(invKv)
-#undef DC_PUT
-}
-struct SysAugLds {
-    typedef double real;
-    typedef DayConstLds dayconst;
-    static constexpr int NS = 11;
-    static constexpr int RESYNC_EVERY = 8;
-    static constexpr int N_ERR = 7;
-    static constexpr bool QUAD_IN_NORM = false;
-    static __device__ __forceinline__ void resync(double (&z)[11], const DayConstLds& c)
-    {
-        const double lq = sp_log(z[3]);
-        sp_exp2(c(DC_bQ) * lq, c(DC_kM) * lq, z[9], z[10]);
-    }
-    static __device__ __forceinline__ void f(const double (&z)[11], const DayConstLds& c, double (&dz)[11], double (&q)[4])
-    {
-        const double fc = c(DC_fc), inv_d = c(DC_inv_d);
-        const double uA = z[0] - fc, uS = z[1] - fc;
-        const double QsA = uA * gate(uA, inv_d) * c(DC_invTsA);
-        const double QsS = uS * gate(uS, inv_d) * c(DC_invTsS);
-        const double aE = c(DC_aE), c0 = c(DC_c0);
-        dz[0] = __builtin_fma(aE, z[7] - 1.0, c0) - QsA;
-        dz[1] = __builtin_fma(aE, z[8] - 1.0, c0) - QsS;
-        const double Qsum = __builtin_fma(c(DC_fA), QsA, c(DC_fS) * QsS);
-        const double Qgmin = c(DC_Qgmin);
-        const double ug = __builtin_fma(z[2], c(DC_invTg), -Qgmin);
-        const double Qg = __builtin_fma(gate(ug, c(DC_inv_dg)), ug, Qgmin);
-        dz[2] = __builtin_fma(c(DC_beta), Qsum, -Qg);
-        const double Qr = z[3], pb = z[9], pk = z[10];
-        const double inflow = __builtin_fma(c(DC_omb), Qsum, c(DC_qin)) + Qg - Qr;
-        const double dQr = inflow * c(DC_cQ) * pb;
-        dz[3] = dQr;
-        const double kap = pb * c(DC_invKv);
-        const double oM = z[4] * kap, oT = z[5] * kap, oP = z[6] * kap;
-        dz[4] = __builtin_fma(c(DC_Esum), pk, c(DC_MsusUS)) - oM;
-        dz[5] = __builtin_fma(c(DC_tA), QsA, __builtin_fma(c(DC_tS), QsS, __builtin_fma(c(DC_tg), Qg, c(DC_tconst)))) - oT;
-        dz[6] = __builtin_fma(c(DC_cPP), pk, c(DC_PPrUS)) - oP;
-        const double mu = c(DC_mu);
-        dz[7] = -mu * z[7] * dz[0];
-        dz[8] = -mu * z[8] * dz[1];
-        const double r = dQr * sp_rcp1(Qr);
-        dz[9] = c(DC_bQ) * pb * r;
-        dz[10] = c(DC_kM) * pk * r;
-        q[0] = Qr; q[1] = oM; q[2] = oT; q[3] = oP;
-    }
-};
-#endif
 
 // fp32 working precision for the augmented system (SIMPLYP_INTEG_CASHKARP_AUG_F32, BASELINE config C5): the 11 stage
 // states and all stage arithmetic in float (half the registers, twice the VALU rate once two waves share a SIMD);
@@ -726,9 +675,6 @@ constexpr int CKPT_N = 16;    // y[8], Plab_A, TDPs_A, Plab_NC, TDPs_NC, conc_A,
 
 template <int INTEG, bool SNOW>
 __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, double* s_E, double* s_T, int* s_doy,
-#ifdef SIMPLYP_EXP_LDS_DAYCONST
-                                         double* s_dc,
-#endif
                                          const int lane, const int slot_raw, const int* reaches, const int n_reaches,
                                          const int d_begin, const int d_end, double* ckpt)
 {
@@ -828,6 +774,8 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
         c.bQ = b_Q; c.kM = k_M;
         c.tg = MPv(SIMPLYP_PM_TDPG) * A_catch;                                                    // :163
         c.invKv = 1.0 / Kv;
+        c.wA0 = -fc * c.invTsA; c.wS0 = -fc * c.invTsS; c.s0 = -fc * c.inv_d;
+        c.invKvc = c.invKv / c.cQ;
 
         const double slopeA = RPv(SIMPLYP_PR_S_AR, s), slopeIG = RPv(SIMPLYP_PR_S_IG, s), slopeS = RPv(SIMPLYP_PR_S_SN, s);
         const double ES = MPv(SIMPLYP_PM_E_M) * RPv(SIMPLYP_PR_S_REACH, s);
@@ -921,6 +869,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                 // ---- day constants of the right-hand side ----
                 c.c0 = P * (1 - f_quick);
                 c.aE = alpha * PET;
+                c.c0m = c.c0 - c.aE;
                 c.qin = Qq + QrUS;
                 c.Esum = f_Ar * Esus_A + f_IG * Esus_IG + f_S * Esus_S;
                 c.MsusUS = MsusUS;
@@ -977,14 +926,9 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     sp_exp2(-mu * y[0], -mu * y[1], z[7], z[8]);
                     const double lq0 = sp_log(y[4]);
                     sp_exp2(b_Q * lq0, k_M * lq0, z[9], z[10]);
+                    z[9] *= c.cQ;                                        // the state carried is cQ Qr**b_Q (SysAug::f)
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
-#ifdef SIMPLYP_EXP_LDS_DAYCONST
-                    store_dayconst(s_dc, lane, c);
-                    const DayConstLds cl = {(lds_cvd_ptr)(s_dc + lane)};
-                    ck_day<SysAugLds>(z, yq, cl, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
-#else
                     ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
-#endif
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
@@ -1085,24 +1029,13 @@ __device__ __forceinline__ int slot_of_lane(const KernelArgs& a, int group, int 
 }
 
 // fp64 schemes need ~500 registers for the Cash-Karp stages (one wave per SIMD); the fp32 scheme is asked to fit two
-#ifdef SIMPLYP_EXP_LDS_DAYCONST
-#define SIMPLYP_WAVES_PER_SIMD 2
-#define SIMPLYP_DC_DECL __shared__ double s_dc[DC_N * WAVE];
-#define SIMPLYP_DC_ARG s_dc,
-#else
-#define SIMPLYP_WAVES_PER_SIMD 1
-#define SIMPLYP_DC_DECL
-#define SIMPLYP_DC_ARG
-#endif
-
 template <int INTEG, bool SNOW>
-__global__ __launch_bounds__(WAVE, SIMPLYP_WAVES_PER_SIMD) void simplyp_chain_kernel(const KernelArgs a)
+__global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs a)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
     __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
-    SIMPLYP_DC_DECL
     const int c0 = a.chain_ptr[blockIdx.y], c1 = a.chain_ptr[blockIdx.y + 1];
     if (a.win_stride > 0) {      // pilot windows: the same short run over different stretches of the forcing
         KernelArgs w = a;
@@ -1111,10 +1044,10 @@ __global__ __launch_bounds__(WAVE, SIMPLYP_WAVES_PER_SIMD) void simplyp_chain_ke
         w.doy = a.doy ? a.doy + off : nullptr;
         w.member_rhs = a.member_rhs + (size_t)blockIdx.z * a.E;
         w.route = a.route ? a.route + (size_t)blockIdx.z * a.win_route_stride : nullptr;
-        run_slot<INTEG, SNOW>(w, s_P, s_E, s_T, s_doy, SIMPLYP_DC_ARG threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+        run_slot<INTEG, SNOW>(w, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
         return;
     }
-    run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, SIMPLYP_DC_ARG threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+    run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1183,13 +1116,12 @@ __device__ __forceinline__ unsigned queue_take_ticket(const QueueArgs& q, int la
 // The persistent loop has a single exit, at its head, on a scalar: with `break`s in the body hipcc (ROCm 7.2)
 // structurised the ticket loop into a lane-masked inner loop that re-ran task 0 forever.
 template <int INTEG, bool SNOW>
-__global__ __launch_bounds__(WAVE, SIMPLYP_WAVES_PER_SIMD) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
+__global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
     __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
-    SIMPLYP_DC_DECL
     const int lane = threadIdx.x;
     const unsigned G = (unsigned)q.n_groups;
     const unsigned n_tasks = (unsigned)q.n_pairs * G;
@@ -1210,7 +1142,7 @@ __global__ __launch_bounds__(WAVE, SIMPLYP_WAVES_PER_SIMD) void simplyp_queue_ke
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int d_begin = c * q.chunk_days;
             const int d_end = min(a.D, d_begin + q.chunk_days);
-            run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, SIMPLYP_DC_ARG lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
+            run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
                             q.ckpt + (size_t)s * CKPT_N * (size_t)a.E);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
