@@ -130,7 +130,9 @@ typedef struct {
     int32_t  time_chunk_days;/* single-reach ensembles, adaptive integrators: run as (time chunk x 64-member group) tasks
                                 pulled by one persistent wave per SIMD, so every SIMD stays busy whatever the members'
                                 relative costs.  0 = auto (chunks of 256 days when the ensemble needs more waves than
-                                the chip holds), > 0 = always, with this chunk length (rounded up to 256), < 0 = never.
+                                the chip holds; 64 days for a single-reach run whose output is streamed to the host,
+                                simplyp_stream_out), > 0 = always, with this chunk length (rounded up to a multiple of 64),
+                                < 0 = never.
                                 Results are unchanged bit for bit.                                              */
     int32_t  n_periods;      /* time-reduced output: 0 = one output row per day; > 0 = `out` has n_periods rows per column,
                                 row p = sum over the days d with period_of_day[d] == p (e.g. calendar years) */
@@ -251,11 +253,11 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats);
  * simplyp_stream_out -- deliver the NEXT run's output table to host memory as well (one-shot; NULL disarms).
  * The reference produces its 25 values per catchment-day in host memory (model.py:644, :721-724); an ensemble's table is
  * tens of GB, so the copy is overlapped with the computation: adaptive integrators then run through the time-chunk task
- * queue (opts.time_chunk_days = 0 behaves like 256), the wave that finishes the last task of a time chunk raises a flag in
- * pinned host memory, and a host thread of the library enqueues that chunk's rows (one contiguous block per column) on a
+ * queue (opts.time_chunk_days = 0 then means 64-day chunks for a single reach, 256 for a network), the wave that finishes the
+ * last task of a time chunk raises a flag in pinned host memory, and a host thread of the library enqueues that chunk's rows (one contiguous block per column) on a
  * second HIP stream while later chunks compute.  simplyp_sync / simplyp_run return once the last byte is in `host_out`;
  * stats.d2h_tail_ms is what the copy added after the last launch.  Runs without time chunks (RK4, opts.time_chunk_days < 0,
- * time-reduced rows, D <= 256) copy the whole table after the last launch.
+ * time-reduced rows, runs no longer than one chunk) copy the whole table after the last launch.
  *   host_out    host  same layout and size as `out` (simplyp_out_bytes); pinned memory (simplyp_host_alloc) for the copy
  *                     engine to run at PCIe speed beside the kernel -- pageable memory works, slowly
  *   host_bytes  capacity of host_out, checked against the table size at the run

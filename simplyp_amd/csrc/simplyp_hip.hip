@@ -359,6 +359,8 @@ void copier_main(simplyp_ctx* ctx)
             fprintf(stderr, "[simplyp] copier: chunk %d ready=%u over=%d at %.1f ms\n", c, ctx->host_ready[c], (int)run_over,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count());
         const size_t d0 = (size_t)c * p.chunk_days, nd = std::min<size_t>(p.chunk_days, p.D - d0);
+        // (one plain copy per column: a pitched hipMemcpy2DAsync per chunk does not overlap the persistent kernel at all on this
+        // stack -- 1509 ms per pass instead of 803, profiles/r02_experiments.md)
         for (int j = 0; j < p.ncols; ++j) {
             const size_t off = ((size_t)j * p.D + d0) * p.row_doubles;
             hipError_t err = hipMemcpyAsync(p.host + off, p.dev + off, nd * p.row_doubles * sizeof(double),
@@ -698,10 +700,11 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     // A short pilot run measures each member's cost; members are then handed to lane slots in order of
     // decreasing cost, so (a) the lanes of a wave need similar step counts and (b) the dispatcher starts
     // the long waves first and back-fills with the short ones (longest-processing-time-first).
-    int chunk_days = opts->time_chunk_days > 0 ? opts->time_chunk_days : 256;
-    chunk_days = ((chunk_days + simplyp::TILE_D - 1) / simplyp::TILE_D) * simplyp::TILE_D;
-    // (a streamed output wants time chunks: their rows travel to the host while later chunks compute)
+    // (a streamed output wants time chunks: their rows travel to the host while later chunks compute -- and short ones, so that
+    // the first copy starts early: the copies, not the kernel, bound a streamed pass; 64 days cost ~0.4 % in task overhead)
     const bool stream_chunks = host_out && opts->n_periods == 0;
+    int chunk_days = opts->time_chunk_days > 0 ? opts->time_chunk_days : ((stream_chunks && S == 1) ? 64 : 256);
+    chunk_days = ((chunk_days + 63) / 64) * 64;
     bool want_queue = opts->integrator != SIMPLYP_INTEG_RK4 && D > chunk_days &&
         (opts->time_chunk_days > 0 || (stream_chunks && opts->time_chunk_days == 0) ||
          (opts->time_chunk_days == 0 && ((S == 1 && (int)gx > ctx->n_simd_slots) || (S > 1 && (int)gx < ctx->n_simd_slots))));
