@@ -47,8 +47,11 @@ struct simplyp_ctx {
     DeviceBuf queue;          // ticket, error, done[n_groups] (uint32) | ckpt[CKPT_N][E] (double)
     // streamed output (simplyp_stream_out): the armed destination, the chunk flags the queue kernel raises in pinned host
     // memory, and the host thread that turns a raised flag into the D2H copies of that chunk's rows on `copy_stream`
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copy_done = nullptr;
+    static constexpr int N_COPY_STREAMS = 2;            // measured on C3: 1 stream 803 ms per pass, 2: 795, 3: 796, 4: 799
+    hipStream_t copy_stream = nullptr;                  // = copy_streams[0]: carries ev_copy_done
+    hipStream_t copy_streams[N_COPY_STREAMS] = {};      // the chunk copies take these in turn
+    hipEvent_t ev_copy_done = nullptr, ev_copy_join[N_COPY_STREAMS] = {};
+    int n_copy_streams = 2;
     double* stream_host = nullptr;      // armed for the next run (one-shot)
     int64_t stream_host_bytes = 0;
     uint32_t* host_ready = nullptr;     // [host_ready_cap] hipHostMalloc
@@ -348,6 +351,7 @@ void copier_main(simplyp_ctx* ctx)
     // hipEventSynchronize on it (measured: the first query returned when the kernel ended).  The flags live in host memory;
     // "the run is over" comes from simplyp_sync (or the error paths) through `run_over`.
     bool run_over = false;
+    unsigned n_issued = 0;
     const bool dbg = getenv("SIMPLYP_DEBUG") != nullptr;
     for (int c = 0; c < p.n_chunks; ++c) {
         while (!run_over && __atomic_load_n(&ctx->host_ready[c], __ATOMIC_ACQUIRE) == 0u) {
@@ -363,12 +367,18 @@ void copier_main(simplyp_ctx* ctx)
         // stack -- 1509 ms per pass instead of 803, profiles/r02_experiments.md)
         for (int j = 0; j < p.ncols; ++j) {
             const size_t off = ((size_t)j * p.D + d0) * p.row_doubles;
+            // two streams, taken in turn: the launch gap of one copy dispatch hides behind the other stream's transfer
             hipError_t err = hipMemcpyAsync(p.host + off, p.dev + off, nd * p.row_doubles * sizeof(double),
-                                            hipMemcpyDeviceToHost, ctx->copy_stream);
+                                            hipMemcpyDeviceToHost, ctx->copy_streams[n_issued++ % (unsigned)ctx->n_copy_streams]);
             if (err != hipSuccess && !ctx->copy_error) ctx->copy_error = (int)err;
         }
     }
-    hipError_t err = hipEventRecord(ctx->ev_copy_done, ctx->copy_stream);
+    hipError_t err = hipSuccess;
+    for (int i = 1; i < ctx->n_copy_streams && err == hipSuccess; ++i) {        // stream 0 joins the others, then signals
+        err = hipEventRecord(ctx->ev_copy_join[i], ctx->copy_streams[i]);
+        if (err == hipSuccess) err = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_copy_join[i], 0);
+    }
+    if (err == hipSuccess) err = hipEventRecord(ctx->ev_copy_done, ctx->copy_stream);
     if (err != hipSuccess && !ctx->copy_error) ctx->copy_error = (int)err;
 }
 
@@ -433,7 +443,11 @@ int simplyp_ctx_create(int device, simplyp_ctx** out)
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_main);
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_copy_done);
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < simplyp_ctx::N_COPY_STREAMS && err == hipSuccess; ++i) {
+        err = hipStreamCreateWithFlags(&ctx->copy_streams[i], hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&ctx->ev_copy_join[i], hipEventDisableTiming);
+    }
+    ctx->copy_stream = ctx->copy_streams[0];
     if (err == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -473,7 +487,10 @@ void simplyp_ctx_destroy(simplyp_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->run_over.store(1, std::memory_order_release);
     if (ctx->copier.joinable()) ctx->copier.join();
-    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    for (int i = 0; i < simplyp_ctx::N_COPY_STREAMS; ++i) {
+        if (ctx->copy_streams[i]) { (void)hipStreamSynchronize(ctx->copy_streams[i]); (void)hipStreamDestroy(ctx->copy_streams[i]); }
+        if (ctx->ev_copy_join[i]) (void)hipEventDestroy(ctx->ev_copy_join[i]);
+    }
     if (ctx->ev_copy_done) (void)hipEventDestroy(ctx->ev_copy_done);
     if (ctx->host_ready) (void)hipHostFree(ctx->host_ready);
     if (ctx->chunk_count.ptr) (void)hipFree(ctx->chunk_count.ptr);
