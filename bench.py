@@ -225,9 +225,13 @@ def main():
             except engine.EngineError as ex:          # not enough lockable host memory on this node
                 stream_note = "pinned host buffer of %.1f GB not available (%s): table left in HBM" % (out_bytes / 1e9, ex)
 
+    # the pass runs on a torch stream of its own: the library launches on it, and the per-member summaries enqueued behind the
+    # kernel (ensemble.run_sharded) run beside the tail of the streamed copies instead of after it
+    bench_stream = torch.cuda.Stream(device=eng.tdev)
+
     def run_fn(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=None, out_reaches=None, host=None):
         return eng.run(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=forcing_of_member,
-                       out_reaches=out_reaches, out=out, period_of_day=pod, host_out=host)
+                       out_reaches=out_reaches, out=out, period_of_day=pod, host_out=host, defer_sync=True)
 
     def progress(msg):          # long configurations (c4: ~90 s per pass) must show signs of life on stderr
         if rank == 0:
@@ -235,9 +239,12 @@ def main():
 
     def one_step(host):
         progress("pass: %s" % ("streamed to host" if host is not None else "device-resident"))
-        return ensemble.run_sharded(run_fn, dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], opts,
-                                    out_reaches=prob['out_reaches'], sharded_inputs=(args.scaling == 'weak'),
-                                    total_members=e_total if args.scaling == 'weak' else None, host=host)
+        with torch.cuda.stream(bench_stream):
+            r = ensemble.run_sharded(run_fn, dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], opts,
+                                     out_reaches=prob['out_reaches'], sharded_inputs=(args.scaling == 'weak'),
+                                     total_members=e_total if args.scaling == 'weak' else None, host=host)
+        bench_stream.synchronize()
+        return r
 
     def fence():
         if world > 1:

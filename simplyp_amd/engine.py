@@ -265,7 +265,8 @@ class Engine(object):
         return t.to(self.tdev, non_blocking=True).contiguous()
 
     def run(self, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing_of_member=None,
-            out_reaches=None, out=None, member_rhs=None, member_of_slot=None, period_of_day=None, host_out=None):
+            out_reaches=None, out=None, member_rhs=None, member_of_slot=None, period_of_day=None, host_out=None,
+            defer_sync=False):
         """Integrate every (member, reach) through all days on the device.
 
         forcing [n_sets,2,D] (rows P, PET; [n_sets,3,D] = Precipitation, PET, T_air with ``opts.snow``), doy [D], member_params [NP_M,E], reach_params [NP_R,S,E] may be numpy
@@ -278,7 +279,11 @@ class Engine(object):
         the sum of the daily values of that period.  ``host_out``: a C-contiguous float64 numpy array shaped like ``out``
         (page-locked: ``engine.pinned_empty``) that receives the table too, streamed time chunk by time chunk while the
         kernel runs (``simplyp_stream_out``); the call returns when its last byte has arrived
-        (stats: ``streamed_chunks``, ``d2h_tail_ms``, ``wall_ms``).
+        (stats: ``streamed_chunks``, ``d2h_tail_ms``, ``wall_ms``).  ``defer_sync=True`` (needs a non-default torch stream
+        to be current): the call returns as soon as the launches are enqueued (``simplyp_run_async``); work the caller then
+        enqueues on that stream runs after the kernel but BESIDE the tail of the streamed copies; the returned dict holds only
+        ``member_of_slot`` and ``finish`` -- call ``stats.update(stats.pop('finish')())`` to wait (``simplyp_sync``) and get the
+        statistics.
         """
         torch = self.torch
         L = lib()
@@ -325,14 +330,30 @@ class Engine(object):
             if host_out is not None:
                 self._check(L.simplyp_stream_out(self._h, C.c_void_p(host_out.ctypes.data), C.c_int64(host_out.nbytes)),
                             'simplyp_stream_out')
-            rc = L.simplyp_run(self._h, C.byref(dims), C.byref(opts), f.data_ptr(), dy.data_ptr(),
-                               None if pod is None else pod.data_ptr(),
-                               None if fom is None else fom.data_ptr(), mp.data_ptr(), rp.data_ptr(),
-                               ip(up_ptr), ip(up_idx), ip(oreach), n_or, out.data_ptr(), status.data_ptr(),
-                               None if member_of_slot is None else member_of_slot.data_ptr(),
-                               None if member_rhs is None else member_rhs.data_ptr(), C.byref(stats))
+            args = (self._h, C.byref(dims), C.byref(opts), f.data_ptr(), dy.data_ptr(),
+                    None if pod is None else pod.data_ptr(),
+                    None if fom is None else fom.data_ptr(), mp.data_ptr(), rp.data_ptr(),
+                    ip(up_ptr), ip(up_idx), ip(oreach), n_or, out.data_ptr(), status.data_ptr(),
+                    None if member_of_slot is None else member_of_slot.data_ptr(),
+                    None if member_rhs is None else member_rhs.data_ptr())
+            if defer_sync:
+                if not torch.cuda.current_stream(self.tdev).cuda_stream:
+                    raise EngineError("defer_sync needs a non-default torch stream to be current (torch.cuda.stream(...))")
+                rc = L.simplyp_run_async(*args)
+            else:
+                rc = L.simplyp_run(*(args + (C.byref(stats),)))
         self._check(rc, 'simplyp_run')
-        sd = stats.as_dict()
+        if defer_sync:
+            keep = [f, dy, pod, fom, mp, rp, host_out]          # inputs stay alive until the run is over
+
+            def finish():
+                with torch.cuda.device(self.tdev):
+                    self._check(L.simplyp_sync(self._h, C.byref(stats)), 'simplyp_sync')
+                keep.clear()
+                return stats.as_dict()
+            sd = {'finish': finish}
+        else:
+            sd = stats.as_dict()
         if member_of_slot is not None:
             sd['member_of_slot'] = member_of_slot
         return out, status, sd

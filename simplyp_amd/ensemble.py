@@ -130,6 +130,15 @@ def run_sharded(run_fn, forcing, doy, member_params, reach_params, up_ptr, up_id
             by_member = torch.empty_like(summ)            # columns of `out` are lane slots: back to member order
             by_member[..., mos.long()] = summ
             summ = by_member
+        fin = stats.pop('finish', None) if isinstance(stats, dict) else None
+        if fin is not None:
+            # deferred run (Engine.run(defer_sync=True)): the day-sums above were enqueued behind the kernel and run beside the
+            # tail of the streamed copies; now wait for the run (and the last byte of the host table) and take its statistics
+            stats.update(fin())
         res['summaries'] = gather_to_root(summ, E, group, widths=widths)
         res['all_status'] = gather_to_root(status, E, group, widths=widths)
+    else:
+        fin = stats.pop('finish', None) if isinstance(stats, dict) else None
+        if fin is not None:
+            stats.update(fin())
     return res

@@ -237,3 +237,26 @@ def test_thin_waves_are_bitwise_identical(engine0, lanes):
     assert run(engine0, m)[2]['lanes_per_wave'] == 3
     m = perturbed('chain4_val_2004', 300, out_mask=marshal.MASK_REACH5)
     assert run(engine0, m)[2]['lanes_per_wave'] == 64
+
+
+def test_deferred_sync_lets_the_callers_work_run_beside_the_copy_tail(engine0):
+    """Engine.run(defer_sync=True) on a non-default torch stream: the call returns once the launches are enqueued, work the
+    caller enqueues on that stream is ordered behind the kernel (not behind the copies), finish() waits for the run and the
+    host table.  Results equal the synchronous run's; on the default stream the mode is refused."""
+    import torch
+    m = perturbed('tarland_1981_2010_dynamic', 2048, out_mask=marshal.MASK_REACH5)
+    ref, ref_status, ref_stats = run(engine0, m)
+    want = ref.sum(dim=1)
+    host = engine.pinned_empty(tuple(ref.shape))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out, status, st = run(engine0, m, host_out=host, defer_sync=True)
+        assert 'finish' in st and 'kernel_ms' not in st
+        sums = out.sum(dim=1)                     # behind the kernel, beside the copies
+        st.update(st.pop('finish')())
+    s.synchronize()
+    assert st['queued'] == 1 and st['rhs_evals'] == ref_stats['rhs_evals'] and st['streamed_chunks'] > 0
+    assert bool(torch.equal(out, ref)) and bool(torch.equal(sums, want)) and bool(torch.equal(status, ref_status))
+    assert np.array_equal(host, ref.cpu().numpy(), equal_nan=True)
+    with pytest.raises(engine.EngineError, match='non-default torch stream'):
+        run(engine0, m, defer_sync=True)
