@@ -288,3 +288,31 @@ def test_ensemble_overrides_go_through_the_reference_input_checks():
     badm = mp.copy(); badm[marshal.PM_NAMES.index('d_maxE_aut'), 2] = 340.0
     with pytest.raises(AssertionError, match="'d_maxE_aut' must be between 30 and 335"):
         marshal.validate_ensemble(badm, rp, scs)
+
+
+def test_bench_parent_launches_its_own_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` from a plain shell: the parent builds a torch.distributed.run command for N
+    ranks on 127.0.0.1 and relays its exit code; nothing GPU-related is imported before that.  Also: the config table is
+    consistent and the kernel-source hash is stable."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '2', '--scaling', 'strong'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '4', '--steps', '2', '--scaling', 'strong']
+    assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+    assert set(bench.CONFIGS) == {'c2', 'c3', 'c4', 'c5'} and bench.CONFIGS['c2']['bytes_per_cd'] == 216.0
+    assert bench.CONFIGS['c3']['bytes_per_cd'] == 56.0 and not bench.CONFIGS['c5']['parity_grade']
+    assert bench.kernel_source_hash() == bench.kernel_source_hash() and len(bench.kernel_source_hash()) == 16
