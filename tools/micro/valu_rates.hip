@@ -6,7 +6,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-enum { FMA64, MUL64, ADD64, MAX64, MIN64, RCP64, CMPSEL64, CVT6432, FMA32, PKFMA32, RCP32, EXP32, LOG32, FMA64_SMOV2, FMA64_SNOP, N_OPS };
+enum { FMA64_DEP1, FMA64_DEP2, FMA64_DEP4, FMA64, MUL64, ADD64, MAX64, MIN64, RCP64, CMPSEL64, CVT6432, FMA32, PKFMA32, RCP32, EXP32, LOG32, FMA64_SMOV2, FMA64_SNOP, N_OPS };
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 template <int OP>
@@ -23,6 +23,9 @@ __global__ __launch_bounds__(64, 1) void k(double* out, long long* cyc, int iter
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
+                if (OP == FMA64_DEP1) a[0] = __builtin_fma(a[0], c1, c2);                     // one chain: every FMA waits for the one before
+                if (OP == FMA64_DEP2) a[i & 1] = __builtin_fma(a[i & 1], c1, c2);             // two interleaved chains
+                if (OP == FMA64_DEP4) a[i & 3] = __builtin_fma(a[i & 3], c1, c2);             // four
                 if (OP == FMA64) a[i] = __builtin_fma(a[i], c1, c2);
                 if (OP == MUL64) a[i] = a[i] * c1;
                 if (OP == ADD64) a[i] = a[i] + c2;
@@ -83,6 +86,9 @@ int main()
     CHECK(hipMalloc(&cyc, 2048 * sizeof(long long)));
     int dev = 0; hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, dev));
     printf("%s, %d CUs, clock %.0f MHz (1 cycle = %.3f ns at that clock)\n", p.name, p.multiProcessorCount, p.clockRate / 1e3, 1e6 / p.clockRate);
+    run<FMA64_DEP1>("v_fma_f64, 1 dependent chain", out, cyc, 0);
+    run<FMA64_DEP2>("v_fma_f64, 2 interleaved chains", out, cyc, 0);
+    run<FMA64_DEP4>("v_fma_f64, 4 interleaved chains", out, cyc, 0);
     run<FMA64>("v_fma_f64", out, cyc, 0);
     run<MUL64>("v_mul_f64", out, cyc, 0);
     run<ADD64>("v_add_f64", out, cyc, 0);
