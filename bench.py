@@ -225,6 +225,14 @@ def main():
             except engine.EngineError as ex:          # not enough lockable host memory on this node
                 stream_note = "pinned host buffer of %.1f GB not available (%s): table left in HBM" % (out_bytes / 1e9, ex)
 
+    if world > 1 and not args.no_stream:
+        # all ranks or none: the legs below contain collectives, so the ranks must agree on which legs they run
+        ok = torch.tensor([1 if host_out is not None else 0], dtype=torch.int32, device=eng.tdev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and host_out is not None:
+            host_out = None
+            stream_note = "another rank could not page-lock its staging buffer: table left in HBM on every rank"
+
     # the pass runs on a torch stream of its own: the library launches on it, and the per-member summaries enqueued behind the
     # kernel (ensemble.run_sharded) run beside the tail of the streamed copies instead of after it
     bench_stream = torch.cuda.Stream(device=eng.tdev)
