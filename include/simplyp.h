@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 12
+#define SIMPLYP_ABI_VERSION 13
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -147,6 +147,14 @@ typedef struct {
                                 to fill the chip's SIMDs with full waves under an adaptive integrator is spread over more,
                                 thinner waves: a wave's day costs the attempts of its slowest lane), 1..64 = as given.
                                 Results are unchanged bit for bit.                                               */
+    int32_t  lanes_per_member;/* lanes of a wavefront that work on one member: 1, or 4 (integrator 2 only) = a member's Cash-Karp
+                                attempt spread over a DPP quad -- one lane each for the two soil boxes, the groundwater and the
+                                reach; stage sums, error norm and state update three components per lane instead of eleven --
+                                which halves the time of an attempt.  0 = auto: 4 for a single-reach ensemble so small
+                                (4 E <= 64 x SIMDs, i.e. E <= 16 384 on MI355X) that the run is bound by one member's serial
+                                chain of attempts rather than by throughput, else 1.  lanes_per_wave then counts member
+                                slots of 4 lanes (at most 16).  Results are unchanged bit for bit for every member whose
+                                status is 0.                                                                     */
 } simplyp_opts;
 
 typedef struct {
@@ -161,7 +169,7 @@ typedef struct {
     int32_t  balanced;       /* 1 when the cost-sorted member order was used                */
     int32_t  queued;         /* 1 when the time-chunk task queue kernel ran                  */
     int32_t  lanes_per_wave; /* member slots per wavefront the run used (opts.lanes_per_wave)                     */
-    int32_t  reserved;
+    int32_t  lanes_per_member;/* lanes per member the run used (opts.lanes_per_member): 1 or 4                          */
     int32_t  streamed_chunks;/* simplyp_stream_out: time chunks whose device-to-host copy started while the kernel was still
                                 running (0 = the table was copied after the last launch)                           */
     double   d2h_tail_ms;    /* simplyp_stream_out: device time between the end of the last launch and the last output

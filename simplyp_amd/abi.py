@@ -2,7 +2,7 @@
 
 import ctypes as C
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1
@@ -26,13 +26,14 @@ class Opts(C.Structure):
                 ('run_mode_cal', C.c_int32), ('sc_qr0', C.c_int32), ('out_mask', C.c_uint32),
                 ('step_len', C.c_double), ('project_vr', C.c_int32), ('balance', C.c_int32),
                 ('balance_pilot_days', C.c_int32), ('out_slot_order', C.c_int32),
-                ('time_chunk_days', C.c_int32), ('n_periods', C.c_int32), ('snow', C.c_int32), ('lanes_per_wave', C.c_int32)]
+                ('time_chunk_days', C.c_int32), ('n_periods', C.c_int32), ('snow', C.c_int32), ('lanes_per_wave', C.c_int32),
+                ('lanes_per_member', C.c_int32)]
 
 
 class Stats(C.Structure):
     _fields_ = [('rhs_evals', C.c_uint64), ('steps', C.c_uint64), ('rejected', C.c_uint64),
                 ('kernel_ms', C.c_double), ('pilot_ms', C.c_double), ('simt_efficiency', C.c_double), ('n_launches', C.c_int32), ('balanced', C.c_int32),
-                ('queued', C.c_int32), ('lanes_per_wave', C.c_int32), ('reserved', C.c_int32), ('streamed_chunks', C.c_int32),
+                ('queued', C.c_int32), ('lanes_per_wave', C.c_int32), ('lanes_per_member', C.c_int32), ('streamed_chunks', C.c_int32),
                 ('d2h_tail_ms', C.c_double), ('wall_ms', C.c_double)]
 
     def as_dict(self):
@@ -69,7 +70,7 @@ GOF_STATS = ['N obs', 'NSE', 'log NSE', 'r2', 'Bias (%)', 'nRMSD (%)', 'sum_log_
 # control on the augmented (transcendental-free) form of the system, at the tolerance that meets
 # the <= 1e-6 parity bar against odeint(rtol=atol=1e-12) with a 10x margin.
 DEFAULT_SOLVER = dict(integrator='cashkarp_aug', substeps=8, rtol=1e-8, atol=1e-12, max_steps=4000, project_vr=1,
-                      balance=2, balance_pilot_days=0, out_slot_order=0, time_chunk_days=0, lanes_per_wave=0)
+                      balance=2, balance_pilot_days=0, out_slot_order=0, time_chunk_days=0, lanes_per_wave=0, lanes_per_member=0)
 
 
 def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=True, sc_qr0=0,
@@ -91,6 +92,7 @@ def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=
     o.out_slot_order = int(s['out_slot_order'])
     o.time_chunk_days = int(s['time_chunk_days'])
     o.lanes_per_wave = int(s['lanes_per_wave'])
+    o.lanes_per_member = int(s['lanes_per_member'])
     o.dynamic_epc0 = int(bool(dynamic_epc0))
     o.dynamic_erod = int(bool(dynamic_erod))
     o.run_mode_cal = int(bool(run_mode_cal))

@@ -70,6 +70,7 @@ struct simplyp_ctx {
     bool copy_pending = false;
     std::chrono::steady_clock::time_point t_begin;
     int lanes = 64;           // member slots per wavefront of the last run
+    int team = 1;             // lanes per member of the last run (1, or 4 = one member per DPP quad)
     int queued = 0;           // last run used the task-queue kernel
     int n_simd_slots = 1024;  // CUs x 4 SIMDs: wave slots at one resident wave per SIMD
     int balanced = 0;         // last run used the cost-sorted member order
@@ -402,6 +403,10 @@ int check_args(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* o
         return fail(ctx, SIMPLYP_ERR_ARG, "Cash-Karp needs rtol > 0, atol >= 0, max_steps >= 1");
     if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32 && opts->rtol < 1e-6)
         return fail(ctx, SIMPLYP_ERR_ARG, "fp32 stages cannot resolve rtol < 1e-6 (got %g): use integrator 2", opts->rtol);
+    if (opts->lanes_per_member != 0 && opts->lanes_per_member != 1 && opts->lanes_per_member != 4)
+        return fail(ctx, SIMPLYP_ERR_ARG, "lanes_per_member must be 0 (auto), 1 or 4 (got %d)", opts->lanes_per_member);
+    if (opts->lanes_per_member == 4 && opts->integrator != SIMPLYP_INTEG_CASHKARP_AUG)
+        return fail(ctx, SIMPLYP_ERR_ARG, "lanes_per_member = 4 exists for integrator 2 (Cash-Karp on the augmented system) only");
     if (!(opts->step_len > 0.0)) return fail(ctx, SIMPLYP_ERR_ARG, "step_len must be > 0");
     if (opts->sc_qr0 < 0 || opts->sc_qr0 >= dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "sc_qr0 out of range");
     if ((opts->out_mask & SIMPLYP_MASK_ALL) == 0u || (opts->out_mask & ~SIMPLYP_MASK_ALL) != 0u)
@@ -675,9 +680,20 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     // Member slots per wavefront.  64 unless the ensemble cannot fill the chip with full waves: a single-reach ensemble under an
     // adaptive integrator is then spread over as many waves as there are SIMDs (a wave's day costs its slowest lane's attempts;
     // idle SIMDs cost nothing).  Results do not depend on it (members are independent).
-    int lanes = simplyp::WAVE;
-    if (opts->lanes_per_wave > 0) lanes = std::min<int>(simplyp::WAVE, opts->lanes_per_wave);
-    else if (opts->integrator != SIMPLYP_INTEG_RK4 && S == 1 && (E + simplyp::WAVE - 1) / simplyp::WAVE < ctx->n_simd_slots)
+    // Lanes per member: 1, or 4 -- a member's Cash-Karp attempt spread over a DPP quad (ck_day_quad: ~2 x shorter attempts,
+    // bit-identical results) -- when a single-reach ensemble is so small that even then every member gets a lane slot of a
+    // resident wave: the run is bound by one member's serial chain of attempts, not by throughput.
+    int team = 1;
+    if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG &&
+        (opts->lanes_per_member == 4 ||
+         (opts->lanes_per_member == 0 && S == 1 && (long long)E * 4 <= (long long)simplyp::WAVE * ctx->n_simd_slots)))
+        team = 4;
+    a.team_shift = team == 4 ? 2 : 0;
+    ctx->team = team;
+    const int max_lanes = simplyp::WAVE / team;
+    int lanes = max_lanes;
+    if (opts->lanes_per_wave > 0) lanes = std::min<int>(max_lanes, opts->lanes_per_wave);
+    else if (opts->integrator != SIMPLYP_INTEG_RK4 && S == 1 && (E + max_lanes - 1) / max_lanes < ctx->n_simd_slots)
         lanes = std::max(1, (E + ctx->n_simd_slots - 1) / ctx->n_simd_slots);
     a.lanes = lanes;
     ctx->lanes = lanes;
@@ -686,15 +702,16 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     // one launch of the chain kernel: k.chain_ptr / k.chain_reach describe n_chains mutually independent chains
     auto launch_chains = [&](const simplyp::KernelArgs& k, unsigned n_chains, unsigned n_windows = 1u) -> int {
         dim3 grid(gx, n_chains, n_windows), block(simplyp::WAVE, 1, 1);
-#define SIMPLYP_LAUNCH_CHAIN(INTEG)                                                                                   \
-    do {                                                                                                              \
-        if (snow) hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, true>), grid, block, 0, ctx->stream, k);   \
-        else hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, false>), grid, block, 0, ctx->stream, k);       \
+#define SIMPLYP_LAUNCH_CHAIN(INTEG, TEAM)                                                                                   \
+    do {                                                                                                                    \
+        if (snow) hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, true, TEAM>), grid, block, 0, ctx->stream, k);   \
+        else hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<INTEG, false, TEAM>), grid, block, 0, ctx->stream, k);       \
     } while (0)
-        if (opts->integrator == SIMPLYP_INTEG_RK4) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_RK4);
-        else if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP);
-        else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG_F32);
-        else SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG);
+        if (opts->integrator == SIMPLYP_INTEG_RK4) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_RK4, 1);
+        else if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP, 1);
+        else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG_F32, 1);
+        else if (team == 4) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG, 4);
+        else SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG, 1);
 #undef SIMPLYP_LAUNCH_CHAIN
         HIP_TRY(ctx, hipGetLastError());
         return SIMPLYP_OK;
@@ -905,14 +922,15 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
             unsigned workers = (unsigned)std::min<long long>(n_tasks, ctx->n_simd_slots);
             if (const char* w_env = getenv("SIMPLYP_QUEUE_WORKERS")) workers = std::max(1u, std::min(workers, (unsigned)strtoul(w_env, nullptr, 10)));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
-#define SIMPLYP_LAUNCH_QUEUE(INTEG)                                                                                                       \
-    do {                                                                                                                                  \
-        if (snow) hipLaunchKernelGGL((simplyp::simplyp_queue_kernel<INTEG, true>), dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);  \
-        else hipLaunchKernelGGL((simplyp::simplyp_queue_kernel<INTEG, false>), dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);      \
+#define SIMPLYP_LAUNCH_QUEUE(INTEG, TEAM)                                                                                                       \
+    do {                                                                                                                                        \
+        if (snow) hipLaunchKernelGGL((simplyp::simplyp_queue_kernel<INTEG, true, TEAM>), dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);  \
+        else hipLaunchKernelGGL((simplyp::simplyp_queue_kernel<INTEG, false, TEAM>), dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);      \
     } while (0)
-            if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP);
-            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG_F32);
-            else SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG);
+            if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP, 1);
+            else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG_F32, 1);
+            else if (team == 4) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG, 4);
+            else SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG, 1);
 #undef SIMPLYP_LAUNCH_QUEUE
             HIP_TRY(ctx, hipGetLastError());
             if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] queue kernel launched: S=%d G=%d pairs=%zu chunk=%d ring=%d workers=%u max_polls=%u\n", S, G, pair_idx.size(), chunk_days, ring_chunks, workers, q.max_polls);
@@ -1021,12 +1039,14 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->rhs_evals = c[0]; stats->steps = c[1]; stats->rejected = c[2];
         stats->kernel_ms = ms;
         // lanes doing useful work per issued attempt: (attempts summed over lanes) / (64 x wave-level attempts)
-        stats->simt_efficiency = c[3] ? (double)(c[0] / 6) / (64.0 * (double)c[3]) : 1.0;     // (of all 64 lanes, also when a wave carries fewer members)
+        // (of all 64 lanes, also when a wave carries fewer members; a member spread over a quad occupies four)
+        stats->simt_efficiency = c[3] ? (double)(c[0] / 6) * ctx->team / (64.0 * (double)c[3]) : 1.0;
         stats->pilot_ms = ctx->balanced ? ms_pilot : 0.0;
         stats->n_launches = ctx->n_launches;
         stats->balanced = ctx->balanced;
         stats->queued = ctx->queued;
         stats->lanes_per_wave = ctx->lanes;
+        stats->lanes_per_member = ctx->team;
         stats->streamed_chunks = copied ? ctx->streamed_chunks : 0;
         stats->d2h_tail_ms = copied ? ms_tail : 0.0;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();

@@ -30,7 +30,8 @@ constexpr int TILE_D = 256;     // days of forcing staged in LDS at a time (256*
 
 struct KernelArgs {
     int E, S, D, n_sets;
-    int lanes;                      // member slots per wavefront (1..64): lane l of group g owns slot g*lanes + l, lanes >= `lanes` idle
+    int lanes;                      // member slots per wavefront (1..64 / team): lanes [l*team, (l+1)*team) of group g own slot g*lanes + l, the rest idle
+    int team_shift;                 // log2(lanes per member): 0, or 2 when a member is spread over a quad (opts.lanes_per_member = 4)
     int D_stride;                   // row stride of `forcing` in days (D of the full run)
     const int* perm;                // [E] member handled by each lane slot, or nullptr = identity
     int out_by_slot;                // 1: `out` columns are lane slots (coalesced), 0: member ids
@@ -645,6 +646,298 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 }
 
 // ---------------------------------------------------------------------------------------
+// One member over FOUR lanes (opts.lanes_per_member = 4; scheme 2 only).
+//
+// An ensemble that cannot fill the chip's 1024 SIMDs even with one member per wave-lane-slot (BASELINE config C2: 1024
+// members; a 100 000-member ensemble split over 8 GPUs: 12 500 each) runs at the latency of ONE member's serial chain of
+// attempts, with 63 (or 51) of a wave's 64 lanes idle.  Here a member's Cash-Karp attempt is spread over the four lanes of a
+// DPP quad, component-wise:
+//
+//      lane j of the quad      slot 0 (store)   slot 1 (carried function)     slot 2 (reach mass)   daily integral
+//      0  soil box A           VsA              EA = exp(-mu VsA)             Msus                  Msus Qr/Vr
+//      1  soil box S           VsS              ES = exp(-mu VsS)             TDPr                  TDPr Qr/Vr
+//      2  groundwater          Vg               pk = Qr**k_M                  PPr                   PPr Qr/Vr
+//      3  reach                Qr               pbc = cQ Qr**b_Q              (none: stays 0)       Qr
+//
+// so the stage sums, the error norm and the state update cost 3 components per lane instead of 11, and the right-hand side
+// is evaluated "one sub-system per lane": the three smooth-step gates (two soil boxes, groundwater) are the same
+// instructions on different operands, likewise the three mass balances and the four carried-function derivatives; what a
+// lane needs from its quad mates (QsA, QsS, Qg, pbc, pk, the reach's dQr/Qr) travels by DPP quad_perm moves (two 32-bit
+// moves per double, no LDS).  Per-lane coefficient tables (QuadConst) with 0 / 1 / -1 entries select each lane's formula
+// through FMAs that are exact for those entries, so EVERY value is produced by the same IEEE operations in the same order as
+// in SysAug::f / ck_day<SysAug>: results are bit-identical to the one-lane kernels (tested), step sequence included.
+// ~375 issue slots per attempt instead of ~750.
+
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v)
+{
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// quad_perm control words: lane j of every quad reads lane sel_j of the same quad
+#define SP_QP(s0, s1, s2, s3) ((s0) | ((s1) << 2) | ((s2) << 4) | ((s3) << 6))
+template <int J> __device__ __forceinline__ double quad_bcast(double v) { return quad_perm<SP_QP(J, J, J, J)>(v); }
+
+struct QuadConst {
+    // gate of slot 0:  w = fma(x0, cw, w0);  s = clamp(fma(j == 2 ? w : x0, cs, s0c));  Q = fma(s s (3 - 2 s), w, q0)
+    double cw, w0, cs, s0c, q0;
+    // slot-0 derivative:  t = fma(cA, j < 2 ? x1 : Qsum, fma(nG, Qg, cB));  d0 = fma(nZ, x0, fma(nQ, Q, fma(mP, Qg, t))) * fma(mP, x1, m012)
+    double cA, cB, nG, mP, nQ, nZ, m012;
+    // slot-1 derivative:  d1 = (c1 x1) * rate
+    double c1;
+    // slot-2 derivative:  d2 = fma(mK, pk, fma(mA, QsA, fma(mS, QsS, fma(mG, Qg, m4)))) - x2 kap
+    double mG, m4, mS, mA, mK;
+    // the same for every lane
+    double fA, fS, invKvc;
+};
+
+__device__ __forceinline__ double sel4(int j, double a0, double a1, double a2, double a3)
+{
+    return j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3));
+}
+
+__device__ __forceinline__ QuadConst quad_const(const DayConst& c, int j)
+{
+    QuadConst k;
+    k.cw = sel4(j, c.invTsA, c.invTsS, c.invTg, 0.0);
+    k.w0 = sel4(j, c.wA0, c.wS0, -c.Qgmin, 0.0);
+    k.cs = sel4(j, c.inv_d, c.inv_d, c.inv_dg, 0.0);
+    k.s0c = sel4(j, c.s0, c.s0, 0.0, 0.0);
+    k.q0 = sel4(j, -0.0, -0.0, c.Qgmin, 0.0);       // fma(g, w, -0.0) == g * w, sign of zero included
+    k.cA = sel4(j, c.aE, c.aE, c.beta, c.omb);
+    k.cB = sel4(j, c.c0m, c.c0m, 0.0, c.qin);
+    k.nG = sel4(j, 0.0, 0.0, -1.0, 0.0);
+    k.mP = sel4(j, 0.0, 0.0, 0.0, 1.0);
+    k.nQ = sel4(j, -1.0, -1.0, 0.0, 0.0);
+    k.nZ = sel4(j, 0.0, 0.0, 0.0, -1.0);
+    k.m012 = sel4(j, 1.0, 1.0, 1.0, 0.0);
+    k.c1 = sel4(j, -c.mu, -c.mu, c.kM, c.bQ);
+    k.mG = sel4(j, 0.0, c.tg, 0.0, 0.0);
+    k.m4 = sel4(j, c.MsusUS, c.tconst, c.PPrUS, 0.0);
+    k.mS = sel4(j, 0.0, c.tS, 0.0, 0.0);
+    k.mA = sel4(j, 0.0, c.tA, 0.0, 0.0);
+    k.mK = sel4(j, c.Esum, 0.0, c.cPP, 0.0);
+    k.fA = c.fA; k.fS = c.fS; k.invKvc = c.invKvc;
+    return k;
+}
+
+// SysAug::f, one sub-system per lane.  x = this lane's three slots, d = their derivatives, qv = this lane's daily integrand.
+__device__ __forceinline__ void quad_rhs(const double (&x)[3], const QuadConst& k, const bool j_lt2, const bool j_eq2,
+                                         double (&d)[3], double& qv)
+{
+    // smooth-step gate of the store in slot 0: QsA, QsS (:105, :109), Qg (:121-122); lane 3 gets 0
+    const double w = __builtin_fma(x[0], k.cw, k.w0);
+    double s = __builtin_fma(j_eq2 ? w : x[0], k.cs, k.s0c);
+    s = __builtin_fmin(__builtin_fmax(s, 0.0), 1.0);
+    const double Q = __builtin_fma((s * s) * __builtin_fma(-2.0, s, 3.0), w, k.q0);
+    const double QsA = quad_bcast<0>(Q), QsS = quad_bcast<1>(Q), Qg = quad_bcast<2>(Q);
+    const double Qsum = __builtin_fma(k.fA, QsA, k.fS * QsS);
+    // slot 0: dVsA, dVsS (:106, :110), dVg (:124), dQr (:127-130)
+    const double t = __builtin_fma(k.cA, j_lt2 ? x[1] : Qsum, __builtin_fma(k.nG, Qg, k.cB));
+    const double u = __builtin_fma(k.mP, Qg, t);
+    const double v = __builtin_fma(k.nZ, x[0], __builtin_fma(k.nQ, Q, u));
+    d[0] = v * __builtin_fma(k.mP, x[1], k.m012);
+    // slot 1: d exp(-mu Vs) = -mu E dVs;  d (cQ Qr**b_Q), d Qr**k_M = (b_Q | k_M) p dQr/Qr  -- the reach lane's dQr/Qr goes to lane 2
+    const double rq = sp_rcp1(x[0]);
+    const double rr = d[0] * (j_lt2 ? 1.0 : rq);
+    const double rate = quad_perm<SP_QP(0, 1, 3, 3)>(rr);
+    d[1] = (k.c1 * x[1]) * rate;
+    // slot 2: the three reach masses (:141-145, :154-166, :171-178) against Qr/Vr = pbc invKvc
+    const double pbc = quad_bcast<3>(x[1]), pk = quad_bcast<2>(x[1]);
+    const double kap = pbc * k.invKvc;
+    const double o = x[2] * kap;
+    d[2] = __builtin_fma(k.mK, pk, __builtin_fma(k.mA, QsA, __builtin_fma(k.mS, QsS, __builtin_fma(k.mG, Qg, k.m4)))) - o;
+    // daily integrands (:132, :147, :168, :180): Qr on the reach lane (whose slot 2 is empty: o == 0), the mass fluxes on the others
+    qv = __builtin_fma(k.mP, x[0], o);
+}
+
+// ck_day<SysAug> for a quad.  z[11] / yq[4] hold the member's whole state on every lane of the quad, on entry and on return.
+__device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], const DayConst& c,
+                                            const double T, const double rtol, const double atol, int max_steps, double& h_carry,
+                                            CkCounters& cnt, const bool lane_active, const int j)
+{
+    typedef double R;
+    const bool j_lt2 = j < 2, j_eq2 = j == 2, j_eq3 = j == 3;
+    const QuadConst k = quad_const(c, j);
+    R a21 = 1.0 / 5;
+    R a31 = 3.0 / 40, a32 = 9.0 / 40;
+    R a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
+    R a51 = -11.0 / 54, a52 = 5.0 / 2, a53 = -70.0 / 27, a54 = 35.0 / 27;
+    R a61 = 1631.0 / 55296, a62 = 175.0 / 512, a63 = 575.0 / 13824, a64 = 44275.0 / 110592, a65 = 253.0 / 4096;
+    R b1 = 37.0 / 378, b3 = 250.0 / 621, b4 = 125.0 / 594, b6 = 512.0 / 1771;
+    R e1 = 37.0 / 378 - 2825.0 / 27648, e3 = 250.0 / 621 - 18575.0 / 48384,
+      e4 = 125.0 / 594 - 13525.0 / 55296, e5 = -277.0 / 14336, e6 = 512.0 / 1771 - 1.0 / 4;
+#define SP_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
+    SP_KEEP_SCALAR(a21); SP_KEEP_SCALAR(a31); SP_KEEP_SCALAR(a32); SP_KEEP_SCALAR(a41); SP_KEEP_SCALAR(a42); SP_KEEP_SCALAR(a43);
+    SP_KEEP_SCALAR(a51); SP_KEEP_SCALAR(a52); SP_KEEP_SCALAR(a53); SP_KEEP_SCALAR(a54);
+    SP_KEEP_SCALAR(a61); SP_KEEP_SCALAR(a62); SP_KEEP_SCALAR(a63); SP_KEEP_SCALAR(a64); SP_KEEP_SCALAR(a65);
+    SP_KEEP_SCALAR(b1); SP_KEEP_SCALAR(b3); SP_KEEP_SCALAR(b4); SP_KEEP_SCALAR(b6);
+    SP_KEEP_SCALAR(e1); SP_KEEP_SCALAR(e3); SP_KEEP_SCALAR(e4); SP_KEEP_SCALAR(e5); SP_KEEP_SCALAR(e6);
+    R huge = sp_huge<R>(), c11 = (R)1.1;
+    SP_KEEP_SCALAR(huge); SP_KEEP_SCALAR(c11);
+#undef SP_KEEP_SCALAR
+    R t = 0, h = (R)h_carry;
+    if (!(h > (R)0) || h > T) h = T;
+    int trip = 0;
+    unsigned n_alive = 0, n_acc = 0;
+    bool gave_up_today = false;
+    bool alive = true;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) alive = alive && (sp_abs(z[i]) < sp_huge<R>());
+    if (!alive) {
+        cnt.poisoned = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yq[i] = __builtin_nan("");
+    }
+    alive = alive && lane_active;
+
+    // this lane's slots of the member's state, and its daily integral
+    R y[3];
+    y[0] = sel4(j, z[0], z[1], z[2], z[3]);
+    y[1] = sel4(j, z[7], z[8], z[10], z[9]);
+    y[2] = sel4(j, z[4], z[5], z[6], 0.0);
+    double yqv = sel4(j, yq[1], yq[2], yq[3], yq[0]);
+
+    bool any_alive = __any(alive);
+    while (any_alive) {
+    do {
+        ++cnt.wave_trips;
+        const R rem = T - t;
+        R hh = h;
+        hh = (rem < (R)2 * h) ? (R)0.5 * rem : hh;
+        hh = (rem <= c11 * h) ? rem : hh;
+        const bool last_chance = (trip + 1 >= max_steps);
+        if (last_chance) hh = rem;
+        if (!alive) hh = 0;
+
+        R k1[3], k2[3], k3[3], k4[3], k5[3], k6[3], kq, yt[3];
+        R sq;
+        quad_rhs(y, k, j_lt2, j_eq2, k1, kq);
+        sq = b1 * kq;
+        {
+            const R h21 = hh * a21;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) yt[i] = sp_fma(h21, k1[i], y[i]);
+        }
+        quad_rhs(yt, k, j_lt2, j_eq2, k2, kq);
+        {
+            const R h31 = hh * a31, h32 = hh * a32;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) yt[i] = sp_fma(h32, k2[i], sp_fma(h31, k1[i], y[i]));
+        }
+        quad_rhs(yt, k, j_lt2, j_eq2, k3, kq);
+        sq = sp_fma(b3, kq, sq);
+        {
+            const R h41 = hh * a41, h42 = hh * a42, h43 = hh * a43;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                yt[i] = sp_fma(h43, k3[i], sp_fma(h42, k2[i], sp_fma(h41, k1[i], y[i])));
+        }
+        quad_rhs(yt, k, j_lt2, j_eq2, k4, kq);
+        sq = sp_fma(b4, kq, sq);
+        {
+            const R h51 = hh * a51, h52 = hh * a52, h53 = hh * a53, h54 = hh * a54;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                yt[i] = sp_fma(h54, k4[i], sp_fma(h53, k3[i], sp_fma(h52, k2[i], sp_fma(h51, k1[i], y[i]))));
+        }
+        quad_rhs(yt, k, j_lt2, j_eq2, k5, kq);
+        {
+            const R h61 = hh * a61, h62 = hh * a62, h63 = hh * a63, h64 = hh * a64, h65 = hh * a65;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                yt[i] = sp_fma(h65, k5[i], sp_fma(h64, k4[i], sp_fma(h63, k3[i],
+                        sp_fma(h62, k2[i], sp_fma(h61, k1[i], y[i])))));
+        }
+        quad_rhs(yt, k, j_lt2, j_eq2, k6, kq);
+        sq = sp_fma(b6, kq, sq);
+
+        // error norm over the 7 physical states = slots 0 and 2 of the quad (lane 3's slot 2 is identically 0 and adds
+        // nothing); the maximum over the quad is exact in any order.  The finiteness test looks at the increments of the reach
+        // states (Qr, Msus, TDPr, PPr), as ck_day<SysAug>'s `chk` does: a non-finite one makes the lane's error infinite.
+        const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
+        R err = 0;
+        R he_s[3];
+#pragma unroll
+        for (int i = 0; i < 3; i += 2) {
+            const R he = sp_fma(he1, k1[i], sp_fma(he3, k3[i], sp_fma(he4, k4[i], sp_fma(he5, k5[i], he6 * k6[i]))));
+            he_s[i] = he;
+            const R sc = sp_fma(rtol, sp_absmax(y[i], sp_fma(hh, k1[i], y[i])), atol);
+            err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
+        }
+        {
+            const R chk = j_eq3 ? he_s[0] : he_s[2];
+            if (!(sp_abs(chk) < huge)) err = __builtin_inf();
+        }
+        err = sp_max(err, quad_perm<SP_QP(1, 0, 3, 2)>(err));
+        err = sp_max(err, quad_perm<SP_QP(2, 3, 0, 1)>(err));
+        R dq = hh * sq;
+        const bool bad = !(err < huge);
+
+        ++trip;
+        float fac = 0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
+        fac = fminf(fmaxf(fac, 0.2f), 5.0f);
+        const bool accept = alive && !bad && (err <= (R)1 || last_chance);
+        bool give_up = false;
+        n_alive += alive ? 1u : 0u;
+        n_acc += accept ? 1u : 0u;
+        if (last_chance && alive) cnt.capped = true;
+        t = accept ? ((hh == rem) ? T : t + hh) : t;
+        const bool any_bad = __any(alive && bad);
+        if (any_bad) {
+            give_up = alive && bad && (last_chance || hh <= (R)1.0e-9 * T);
+            if (alive && bad) fac = 0.2f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                k1[i] = bad ? (R)0 : k1[i]; k3[i] = bad ? (R)0 : k3[i]; k4[i] = bad ? (R)0 : k4[i]; k6[i] = bad ? (R)0 : k6[i];
+            }
+            dq = bad ? (R)0 : dq;
+        }
+        {
+            const R m = accept ? hh : (R)0;
+            const R hb1 = m * b1, hb3 = m * b3, hb4 = m * b4, hb6 = m * b6;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) y[i] = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], sp_fma(hb1, k1[i], y[i]))));
+            const R mq = accept ? (R)1 : (R)0;
+            yqv = __builtin_fma(mq, dq, yqv);
+        }
+        if (any_bad) {
+            if (give_up) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) y[i] = (R)__builtin_nanf("");
+                yqv = __builtin_nan("");
+                cnt.poisoned = true; gave_up_today = true;
+            }
+        }
+        h = alive ? hh * (R)fac : h;
+        alive = alive && !give_up && (t < T);
+        any_alive = __any(alive);
+    } while (any_alive && (trip % SysAug::RESYNC_EVERY) != 0);
+        // SysAug::resync: pbc (lane 3) and pk (lane 2) from the reach lane's Qr, after every RESYNC_EVERY-th attempt
+        if (any_alive && (trip % SysAug::RESYNC_EVERY) == 0) {
+            const double Qr = quad_bcast<3>(y[0]);
+            const double lq = sp_log(Qr);
+            const double p = sp_exp((j_eq3 ? c.bQ : c.kM) * lq);
+            const double y1 = j_eq3 ? c.cQ * p : (j_eq2 ? p : y[1]);
+            y[1] = alive ? y1 : y[1];
+        }
+    }
+    cnt.rhs += 6u * n_alive;
+    cnt.steps += n_acc;
+    cnt.rejected += n_alive - n_acc - (gave_up_today ? 1u : 0u);
+    h_carry = (double)h;
+
+    // the member's state back on every lane of the quad (the carried functions z[7..10] are re-evaluated at the next day start)
+    z[0] = quad_bcast<0>(y[0]); z[1] = quad_bcast<1>(y[0]); z[2] = quad_bcast<2>(y[0]); z[3] = quad_bcast<3>(y[0]);
+    z[4] = quad_bcast<0>(y[2]); z[5] = quad_bcast<1>(y[2]); z[6] = quad_bcast<2>(y[2]);
+    yq[0] = quad_bcast<3>(yqv); yq[1] = quad_bcast<0>(yqv); yq[2] = quad_bcast<1>(yqv); yq[3] = quad_bcast<2>(yqv);
+}
+#undef SP_QP
+
+// ---------------------------------------------------------------------------------------
 
 __device__ __forceinline__ int nc_type_of(double f_NC_A, double f_NC_S)     // model.py:325-334
 {
@@ -673,12 +966,16 @@ __device__ __forceinline__ void soil_p_update(double P_netInput, double A_catch,
 // kernel (single-reach problems); the chain kernel passes nullptr and runs all days of every reach.
 constexpr int CKPT_N = 16;    // y[8], Plab_A, TDPs_A, Plab_NC, TDPs_NC, conc_A, conc_NC, h_carry, snow depth
 
-template <int INTEG, bool SNOW>
+template <int INTEG, bool SNOW, int TEAM>
 __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, double* s_E, double* s_T, int* s_doy,
                                          const int lane, const int slot_raw, const int* reaches, const int n_reaches,
                                          const int d_begin, const int d_end, double* ckpt)
 {
+    static_assert(TEAM == 1 || (TEAM == 4 && INTEG == SIMPLYP_INTEG_CASHKARP_AUG), "four lanes per member: scheme 2 only");
     const bool active = slot_raw < a.E;
+    // TEAM == 4: the four lanes of a quad share a member slot.  Everything outside the day's integration (day constants, soil P,
+    // end-of-day flows) is computed by all four alike -- same addresses, same values; one of them (`writer`) stores and counts.
+    const bool writer = active && (TEAM == 1 || (lane & (TEAM - 1)) == 0);
     const int slot = active ? slot_raw : a.E - 1;     // inactive lanes shadow the last slot, store nothing
     // Load balancing (host side, simplyp_hip.hip): lane slots may be handed members in order of expected
     // cost.  Parameters, outputs and status are addressed by member id e (a gather / scatter of 8-byte
@@ -928,7 +1225,8 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     sp_exp2(b_Q * lq0, k_M * lq0, z[9], z[10]);
                     z[9] *= c.cQ;                                        // the state carried is cQ Qr**b_Q (SysAug::f)
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
-                    ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
+                    if (TEAM == 4) ck_day_quad(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active, lane & 3);
+                    else ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
@@ -965,7 +1263,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                 }
 
                 // ---- hand the daily series downstream and store the requested columns ----
-                if (active) {
+                if (writer) {
                     if (route_w) {
                         double* r = route_w + ((size_t)d % RD) * E + slot;
                         r[0] = yq[0]; r[RD * E] = yq[1]; r[2 * RD * E] = yq[2]; r[3 * RD * E] = yq[3];
@@ -994,7 +1292,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                 }
             }
         }
-        if (ckpt && d_end < D && active) {      // hand the state to whichever wave runs the next time chunk
+        if (ckpt && d_end < D && writer) {      // hand the state to whichever wave runs the next time chunk
             double* k = ckpt + slot;
 #pragma unroll
             for (int i = 0; i < 8; ++i) k[(size_t)i * E] = y[i];
@@ -1007,7 +1305,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
 #undef RPv
 
     // ---- per-wave solver statistics and member status ----
-    if (!active) { n_rhs = 0; n_steps = 0; n_rej = 0; }
+    if (!writer) { n_rhs = 0; n_steps = 0; n_rej = 0; }
     unsigned long long v0 = n_rhs, v1 = n_steps, v2 = n_rej;
     for (int off = 32; off > 0; off >>= 1) {
         v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off);
@@ -1016,8 +1314,8 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
         atomicAdd(&a.counters[0], v0); atomicAdd(&a.counters[1], v1); atomicAdd(&a.counters[2], v2);
         atomicAdd(&a.counters[3], (unsigned long long)n_trips);      // wave-level attempts (lane 0's count = the wave's)
     }
-    if (active && stat) atomicOr(&a.status[e], stat);
-    if (active && a.member_rhs) atomicAdd(&a.member_rhs[e], n_rhs);      // several chains / time chunks per member
+    if (writer && stat) atomicOr(&a.status[e], stat);
+    if (writer && a.member_rhs) atomicAdd(&a.member_rhs[e], n_rhs);      // several chains / time chunks per member
 }
 
 // Member slot of a lane: group g carries a.lanes consecutive slots; the other lanes of the wave get E (= no member).
@@ -1025,11 +1323,12 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
 // ensemble that cannot fill the chip's 1024 SIMDs with full waves loses nothing by spreading over more, thinner ones.
 __device__ __forceinline__ int slot_of_lane(const KernelArgs& a, int group, int lane)
 {
-    return lane < a.lanes ? group * a.lanes + lane : a.E;
+    const int l = lane >> a.team_shift;
+    return l < a.lanes ? group * a.lanes + l : a.E;
 }
 
 // fp64 schemes need ~500 registers for the Cash-Karp stages (one wave per SIMD); the fp32 scheme is asked to fit two
-template <int INTEG, bool SNOW>
+template <int INTEG, bool SNOW, int TEAM>
 __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs a)
 {
     __shared__ double s_P[TILE_D];
@@ -1044,10 +1343,10 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs
         w.doy = a.doy ? a.doy + off : nullptr;
         w.member_rhs = a.member_rhs + (size_t)blockIdx.z * a.E;
         w.route = a.route ? a.route + (size_t)blockIdx.z * a.win_route_stride : nullptr;
-        run_slot<INTEG, SNOW>(w, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+        run_slot<INTEG, SNOW, TEAM>(w, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
         return;
     }
-    run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+    run_slot<INTEG, SNOW, TEAM>(a, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1115,7 +1414,7 @@ __device__ __forceinline__ unsigned queue_take_ticket(const QueueArgs& q, int la
 
 // The persistent loop has a single exit, at its head, on a scalar: with `break`s in the body hipcc (ROCm 7.2)
 // structurised the ticket loop into a lane-masked inner loop that re-ran task 0 forever.
-template <int INTEG, bool SNOW>
+template <int INTEG, bool SNOW, int TEAM>
 __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
 {
     __shared__ double s_P[TILE_D];
@@ -1142,7 +1441,7 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int d_begin = c * q.chunk_days;
             const int d_end = min(a.D, d_begin + q.chunk_days);
-            run_slot<INTEG, SNOW>(a, s_P, s_E, s_T, s_doy, lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
+            run_slot<INTEG, SNOW, TEAM>(a, s_P, s_E, s_T, s_doy, lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
                             q.ckpt + (size_t)s * CKPT_N * (size_t)a.E);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

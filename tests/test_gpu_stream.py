@@ -229,7 +229,7 @@ def test_thin_waves_are_bitwise_identical(engine0, lanes):
     import torch
     for name, E, solver in (('tarland_2004_dynamic', 150, dict(time_chunk_days=-1)), ('tarland_2004_dynamic', 150, dict(time_chunk_days=256)),
                             ('chain4_val_2004', 70, None)):
-        m = perturbed(name, E, out_mask=marshal.MASK_REACH5, solver=dict(solver or {}, lanes_per_wave=64))
+        m = perturbed(name, E, out_mask=marshal.MASK_REACH5, solver=dict(solver or {}, lanes_per_wave=64, lanes_per_member=1))
         ref, rs, rst = run(engine0, m)
         assert rst['lanes_per_wave'] == 64
         m['opts'].lanes_per_wave = lanes
@@ -237,7 +237,7 @@ def test_thin_waves_are_bitwise_identical(engine0, lanes):
         assert gst['lanes_per_wave'] == lanes and gst['rhs_evals'] == rst['rhs_evals']
         assert bool(torch.equal(got, ref)) and bool(torch.equal(gs, rs))
     # auto: a single-reach ensemble that cannot fill the chip is spread; a reach network keeps full waves
-    m = perturbed('tarland_2004_dynamic', 3000, out_mask=marshal.MASK_REACH5)
+    m = perturbed('tarland_2004_dynamic', 3000, out_mask=marshal.MASK_REACH5, solver=dict(lanes_per_member=1))
     assert run(engine0, m)[2]['lanes_per_wave'] == 3
     m = perturbed('chain4_val_2004', 300, out_mask=marshal.MASK_REACH5)
     assert run(engine0, m)[2]['lanes_per_wave'] == 64
