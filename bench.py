@@ -332,12 +332,14 @@ def main():
                          "streamed_chunks": int(step_stats[-1]['streamed_chunks']),
                          "d2h_gbs_over_run": None if host_out is None else out_bytes / (float(np.mean([s['wall_ms'] for s in step_stats])) * 1e-3) / 1e9,
                          "pcie_spec_gbs": PCIE_SPEC_GBS, "host_numa_node": numa_node, "note": stream_note},
-            "occupancy": {"members_per_wave": lanes, "waves_per_gpu": waves, "simd_slots": 1024, "rounds": waves / 1024.0,
+            "occupancy": {"members_per_wave": lanes, "lanes_per_member": int(stats.get('lanes_per_member', 1) or 1),
+                          "waves_per_gpu": waves, "simd_slots": 1024, "rounds": waves / 1024.0,
                           "note": "rounds < 1: the ensemble cannot fill the chip; the pass then takes as long as its slowest wave, "
                                   "i.e. one member's whole daily series (the latency floor, DESIGN.md section 4)" if waves < 1024 and S == 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "simplyp_%s_kernel<%d, false>" % ("queue" if stats.get('queued') else "chain", opts.integrator),
+                         "kernel": "simplyp_%s_kernel<%d, false, %d>" % ("queue" if stats.get('queued') else "chain", opts.integrator,
+                                                                          int(stats.get('lanes_per_member', 1) or 1)),
                          "kernel_ms": k_ms, "pilot_ms": stats.get('pilot_ms', 0.0),
                          "bytes_per_catchment_day": cfg['bytes_per_cd'], "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the path is fp64-VALU-bound, not HBM-bound: see fp64_valu"},

@@ -8,7 +8,7 @@ extra = []
 if '--' in args:
     i = args.index('--'); extra = args[i + 1:]; args = args[:i]
 src = os.path.join(ROOT, 'simplyp_amd', 'csrc', 'simplyp_hip.hip')
-kern = 'simplyp_queue_kernelILi2ELb0'
+kern = 'simplyp_queue_kernelILi2ELb0ELi1'
 while args:
     a = args.pop(0)
     if a == '--src': src = args.pop(0)
