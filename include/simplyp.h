@@ -150,11 +150,11 @@ typedef struct {
     int32_t  lanes_per_member;/* lanes of a wavefront that work on one member: 1, or 4 (integrator 2 only) = a member's Cash-Karp
                                 attempt spread over a DPP quad -- one lane each for the two soil boxes, the groundwater and the
                                 reach; stage sums, error norm and state update three components per lane instead of eleven --
-                                which halves the time of an attempt.  0 = auto: 4 for a single-reach ensemble so small
-                                (4 E <= 64 x SIMDs, i.e. E <= 16 384 on MI355X) that the run is bound by one member's serial
-                                chain of attempts rather than by throughput, else 1.  lanes_per_wave then counts member
-                                slots of 4 lanes (at most 16).  Results are unchanged bit for bit for every member whose
-                                status is 0.                                                                     */
+                                which makes an attempt ~1.4 x shorter.  0 = auto: 4 for an ensemble so small
+                                (ceil(E / 16) x S <= SIMDs, i.e. E <= 16 384 single-reach members on MI355X) that the run is
+                                bound by one member's serial chain of attempts rather than by throughput, else 1.
+                                lanes_per_wave then counts member slots of 4 lanes (at most 16).  Results are unchanged bit
+                                for bit for every member whose status is 0.                                      */
 } simplyp_opts;
 
 typedef struct {

@@ -680,13 +680,13 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     // Member slots per wavefront.  64 unless the ensemble cannot fill the chip with full waves: a single-reach ensemble under an
     // adaptive integrator is then spread over as many waves as there are SIMDs (a wave's day costs its slowest lane's attempts;
     // idle SIMDs cost nothing).  Results do not depend on it (members are independent).
-    // Lanes per member: 1, or 4 -- a member's Cash-Karp attempt spread over a DPP quad (ck_day_quad: ~2 x shorter attempts,
-    // bit-identical results) -- when a single-reach ensemble is so small that even then every member gets a lane slot of a
-    // resident wave: the run is bound by one member's serial chain of attempts, not by throughput.
+    // Lanes per member: 1, or 4 -- a member's Cash-Karp attempt spread over a DPP quad (ck_day_quad: ~1.4 x shorter attempts,
+    // bit-identical results) -- when the ensemble is so small that even then every (member group, reach) finds a resident wave
+    // of its own: the run is bound by one member's serial chain of attempts, not by throughput.
     int team = 1;
     if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG &&
         (opts->lanes_per_member == 4 ||
-         (opts->lanes_per_member == 0 && S == 1 && (long long)E * 4 <= (long long)simplyp::WAVE * ctx->n_simd_slots)))
+         (opts->lanes_per_member == 0 && (long long)((E + 15) / 16) * S <= (long long)ctx->n_simd_slots)))
         team = 4;
     a.team_shift = team == 4 ? 2 : 0;
     ctx->team = team;

@@ -106,7 +106,7 @@ def test_quad_status_words(engine0):
     assert np.array_equal(got.cpu().numpy()[..., ok], ref.cpu().numpy()[..., ok], equal_nan=True)
 
 
-def test_quad_is_chosen_for_small_single_reach_ensembles_only(engine0):
+def test_quad_is_chosen_for_small_ensembles_only(engine0):
     n_simd = 1024
     m = perturbed('tarland_2004_static', 300, out_mask=marshal.MASK_REACH5)
     st = run(engine0, m)[2]
@@ -117,7 +117,9 @@ def test_quad_is_chosen_for_small_single_reach_ensembles_only(engine0):
     m = perturbed('tarland_2004_static', 16 * n_simd + 1, out_mask=marshal.MASK_REACH5)
     assert run(engine0, m)[2]['lanes_per_member'] == 1
     m = perturbed('chain4_val_2004', 40, out_mask=marshal.MASK_REACH5)
-    assert run(engine0, m)[2]['lanes_per_member'] == 1                        # reach networks: on request only
+    assert run(engine0, m)[2]['lanes_per_member'] == 4                        # reach networks: groups x reaches <= SIMDs
+    m = perturbed('chain4_val_2004', 4097, out_mask=marshal.MASK_REACH5)
+    assert run(engine0, m)[2]['lanes_per_member'] == 1                        # 257 groups x 4 reaches > 1024
     m = perturbed('tarland_2004_static', 40, out_mask=marshal.MASK_REACH5, solver=dict(integrator='cashkarp'))
     assert run(engine0, m)[2]['lanes_per_member'] == 1                        # scheme 2 only
     m['opts'].lanes_per_member = 4

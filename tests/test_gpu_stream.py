@@ -239,7 +239,7 @@ def test_thin_waves_are_bitwise_identical(engine0, lanes):
     # auto: a single-reach ensemble that cannot fill the chip is spread; a reach network keeps full waves
     m = perturbed('tarland_2004_dynamic', 3000, out_mask=marshal.MASK_REACH5, solver=dict(lanes_per_member=1))
     assert run(engine0, m)[2]['lanes_per_wave'] == 3
-    m = perturbed('chain4_val_2004', 300, out_mask=marshal.MASK_REACH5)
+    m = perturbed('chain4_val_2004', 300, out_mask=marshal.MASK_REACH5, solver=dict(lanes_per_member=1))
     assert run(engine0, m)[2]['lanes_per_wave'] == 64
 
 
