@@ -142,3 +142,21 @@ def test_quad_on_the_monte_carlo_distribution_against_the_oracle(engine0, oracle
     want, ws, _ = oracle_lib.run(m['forcing'], m['doy'], m['member_params'][:, :8].copy(), m['reach_params'][:, :, :8].copy(),
                                  m['up_ptr'], m['up_idx'], m['opts'])
     assert helpers.max_rel_err(got.cpu().numpy()[..., :8], want, floor=1e-12) < 10 * m['opts'].rtol
+
+
+def test_quad_with_reduced_rows_slot_order_and_selected_reaches(engine0):
+    """Time-reduced rows (running sums updated by the quad's writer lane only), slot-ordered columns after cost ordering, a
+    subset of output reaches: the same bits as with one lane per member."""
+    import torch
+    m = perturbed('confluence3_nc_2004', 90, out_mask=marshal.MASK_REACH5, solver=dict(balance=1, balance_pilot_days=40, out_slot_order=1))
+    D = m['forcing'].shape[2]
+    pod = (np.arange(D) // 31).astype(np.int32)
+    m['opts'].n_periods = int(pod.max()) + 1
+    res = {}
+    for team in (1, 4):
+        m['opts'].lanes_per_member = team
+        out, status, st = run(engine0, m, period_of_day=pod, out_reaches=[2, 0])
+        assert st['lanes_per_member'] == team and st['balanced'] == 1 and int(status.max()) == 0
+        res[team] = (out, st['member_of_slot'])
+    assert res[4][0].shape == (5, int(pod.max()) + 1, 2, 90)
+    assert bool(torch.equal(res[4][1], res[1][1])) and bool(torch.equal(res[4][0], res[1][0]))
