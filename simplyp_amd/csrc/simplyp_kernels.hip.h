@@ -18,6 +18,8 @@
 //   * the right-hand side is the reference's ode_f (model.py:58-187) with everything that is
 //     constant within a day hoisted into `DayConst`; Qr**b_Q and Qr**k_M share one log.
 //   * no MFMA: the system is 12 scalar fluxes, there is no contraction to put on matrix cores.
+//   * small ensembles (fewer member groups than SIMDs) spread one member over the four lanes of a DPP quad instead
+//     (TEAM = 4, `ck_day_quad`): same operations, bit-identical results, ~1.4 x shorter attempts.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -666,7 +668,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 // moves per double, no LDS).  Per-lane coefficient tables (QuadConst) with 0 / 1 / -1 entries select each lane's formula
 // through FMAs that are exact for those entries, so EVERY value is produced by the same IEEE operations in the same order as
 // in SysAug::f / ck_day<SysAug>: results are bit-identical to the one-lane kernels (tested), step sequence included.
-// ~375 issue slots per attempt instead of ~750.
+// 505 instructions per attempt instead of 747 (tools/isa_stats.py); measured 1.42 x (profiles/r02_experiments.md).
 
 template <int CTRL>
 __device__ __forceinline__ double quad_perm(double v)
