@@ -125,7 +125,10 @@ def build_problem(cfg, n_members, seed_offset, args):
     if cfg == 'c3':
         pr = synthetic.c3_problem(n_members, seed=synthetic.C3_SEED + seed_offset, solver=dict(out_slot_order=1))
     elif cfg == 'c2':
-        pr = synthetic.c3_problem(n_members, solver=dict(out_slot_order=1), out_mask=marshal.MASK_ALL, replicated=True)
+        # replicated members take identical steps, so four members per wave (four quads: the library would spread 1024
+        # members one per wave) cost nothing in lockstep, and their adjacent 8-byte stores fill whole 32-byte sectors
+        # (one member per wave: WRITE_SIZE = 4.2 x the table, profiles/r02_quad_c2)
+        pr = synthetic.c3_problem(n_members, solver=dict(out_slot_order=1, lanes_per_wave=4), out_mask=marshal.MASK_ALL, replicated=True)
     elif cfg == 'c4':
         pr = synthetic.c4_problem(n_members, n_reaches=args.reaches, n_days=args.days or 18262,
                                   seed=synthetic.C4_SEED + seed_offset, solver=dict(out_slot_order=1))
