@@ -33,7 +33,6 @@ constexpr int TILE_D = 256;     // days of forcing staged in LDS at a time (256*
 struct KernelArgs {
     int E, S, D, n_sets;
     int lanes;                      // member slots per wavefront (1..64 / team): lanes [l*team, (l+1)*team) of group g own slot g*lanes + l, the rest idle
-    int team_shift;                 // log2(lanes per member): 0, or 2 when a member is spread over a quad (opts.lanes_per_member = 4)
     int D_stride;                   // row stride of `forcing` in days (D of the full run)
     const int* perm;                // [E] member handled by each lane slot, or nullptr = identity
     int out_by_slot;                // 1: `out` columns are lane slots (coalesced), 0: member ids
@@ -65,6 +64,8 @@ struct KernelArgs {
     long long win_route_stride;     // doubles of routing scratch per window
     int dynamic_epc0, dynamic_erod, run_mode_cal, sc_qr0, project_vr;
     double rtol, atol, step_len;
+    int team_shift;                 // log2(lanes per member): 0, or 2 when a member is spread over a quad (opts.lanes_per_member = 4)
+                                    // (last: the argument block of the one-lane kernels keeps the layout it was tuned with)
 };
 
 // ---------------------------------------------------------------------------------------
