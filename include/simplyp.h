@@ -152,7 +152,9 @@ typedef struct {
                                 reach; stage sums, error norm and state update three components per lane instead of eleven --
                                 which makes an attempt ~1.4 x shorter.  0 = auto: 4 for an ensemble so small
                                 (ceil(E / 16) x S <= SIMDs, i.e. E <= 16 384 single-reach members on MI355X) that the run is
-                                bound by one member's serial chain of attempts rather than by throughput, else 1.
+                                bound by one member's serial chain of attempts rather than by throughput -- and for
+                                single-reach ensembles up to 1.75 x that size (28 672 members), whose quads then share all
+                                SIMDs through the task queue where one-lane waves would occupy a third of them --, else 1.
                                 lanes_per_wave then counts member slots of 4 lanes (at most 16).  Results are unchanged bit
                                 for bit for every member whose status is 0.                                      */
 } simplyp_opts;

@@ -682,11 +682,16 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     // idle SIMDs cost nothing).  Results do not depend on it (members are independent).
     // Lanes per member: 1, or 4 -- a member's Cash-Karp attempt spread over a DPP quad (ck_day_quad: ~1.4 x shorter attempts,
     // bit-identical results) -- when the ensemble is so small that even then every (member group, reach) finds a resident wave
-    // of its own: the run is bound by one member's serial chain of attempts, not by throughput.
+    // of its own: the run is bound by one member's serial chain of attempts, not by throughput.  A single-reach ensemble may be
+    // up to 1.75 x larger than that: its quads then run through the work-conserving task queue in ~1.5 rounds of waves that all
+    // SIMDs share, where the one-lane kernel would keep a third of the SIMDs busy for one long round (measured, MI355X:
+    // 25 000 members 477 against 598 ms, 30 000 members 571 against 600, 40 000 members 759 against 610).
     int team = 1;
+    const long long quad_waves = (long long)((E + 15) / 16) * S;
     if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG &&
         (opts->lanes_per_member == 4 ||
-         (opts->lanes_per_member == 0 && (long long)((E + 15) / 16) * S <= (long long)ctx->n_simd_slots)))
+         (opts->lanes_per_member == 0 && (quad_waves <= (long long)ctx->n_simd_slots ||
+                                          (S == 1 && quad_waves * 4 <= 7LL * ctx->n_simd_slots)))))
         team = 4;
     a.team_shift = team == 4 ? 2 : 0;
     ctx->team = team;

@@ -114,7 +114,10 @@ def test_quad_is_chosen_for_small_ensembles_only(engine0):
     m = perturbed('tarland_2004_static', 16 * n_simd, out_mask=marshal.MASK_REACH5)
     st = run(engine0, m)[2]
     assert st['lanes_per_member'] == 4 and st['lanes_per_wave'] == 16         # the largest ensemble whose quads all find a resident wave
-    m = perturbed('tarland_2004_static', 16 * n_simd + 1, out_mask=marshal.MASK_REACH5)
+    m = perturbed('tarland_2004_static', 28 * n_simd, out_mask=marshal.MASK_REACH5)
+    st = run(engine0, m)[2]
+    assert st['lanes_per_member'] == 4 and st['queued'] == 1                  # up to 1.75 rounds of quads, through the task queue
+    m = perturbed('tarland_2004_static', 28 * n_simd + 1, out_mask=marshal.MASK_REACH5)
     assert run(engine0, m)[2]['lanes_per_member'] == 1
     m = perturbed('chain4_val_2004', 40, out_mask=marshal.MASK_REACH5)
     assert run(engine0, m)[2]['lanes_per_member'] == 4                        # reach networks: groups x reaches <= SIMDs
