@@ -253,7 +253,8 @@ def main():
         with torch.cuda.stream(bench_stream):
             r = ensemble.run_sharded(run_fn, dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], opts,
                                      out_reaches=prob['out_reaches'], sharded_inputs=(args.scaling == 'weak'),
-                                     total_members=e_total if args.scaling == 'weak' else None, host=host)
+                                     total_members=e_total if args.scaling == 'weak' else None,
+                                     member_counts=[e_local] * world if args.scaling == 'weak' else None, host=host)
         bench_stream.synchronize()
         return r
 
@@ -324,7 +325,7 @@ def main():
                        "parity_grade": cfg['parity_grade'],
                        "parallelism": "ensemble shards (ensemble.run_sharded), %d GPU(s), no data-path collective; final gather "
                                       "of per-member summaries over %s" % (world, 'RCCL' if backend == 'nccl' else backend)},
-            "value_includes": ("output table delivered to pinned host memory (streamed per 256-day chunk beside the kernel) + "
+            "value_includes": ("output table delivered to pinned host memory (streamed per time chunk beside the kernel) + "
                                "per-member summaries gathered on rank 0; inputs resident in HBM") if host_out is not None
                               else "output table left in HBM + per-member summaries gathered on rank 0; inputs resident in HBM",
             "value_device_resident": None if elapsed_dev is None else cd_per_step / (elapsed_dev / max(1, min(args.steps, 3))),

@@ -79,7 +79,7 @@ def gather_to_root(local, n_members, group=None, dst=0, widths=None):
 
 def run_sharded(run_fn, forcing, doy, member_params, reach_params, up_ptr, up_idx, opts,
                 forcing_of_member=None, out_reaches=None, group=None, gather=True, sharded_inputs=False,
-                total_members=None, **run_kwargs):
+                total_members=None, member_counts=None, **run_kwargs):
     """Run this rank's member block through ``run_fn`` (normally ``Engine.run``) and gather the
     per-member summaries on rank 0.
 
@@ -87,7 +87,8 @@ def run_sharded(run_fn, forcing, doy, member_params, reach_params, up_ptr, up_id
     each rank takes its contiguous block (strong scaling: a fixed ensemble split over the GPUs).
     ``sharded_inputs=True``: the arrays already are this rank's own block (weak scaling: every rank brings its own
     members); the global ensemble is the concatenation of the blocks in rank order, ``total_members`` its size
-    (default: the sum over the ranks, found with one all_gather of the block sizes).
+    (default: the sum over the ranks, found with one all_gather of the block sizes; ``member_counts`` -- members per rank,
+    the same list on every rank -- saves that exchange when the caller knows it, e.g. inside a timed loop).
     Extra keyword arguments (``out=``, ``host_out=``, ``member_of_slot=`` ...) go to ``run_fn``.
 
     Returns ``dict(bounds, out, status, stats, summaries, all_status)``; ``summaries`` ([n_cols, n_reaches, E_total],
@@ -104,7 +105,11 @@ def run_sharded(run_fn, forcing, doy, member_params, reach_params, up_ptr, up_id
     if sharded_inputs:
         mp, rp, fom = member_params, reach_params, forcing_of_member
         e_local = int(mp.shape[-1])
-        if world > 1:
+        if member_counts is not None:
+            widths = [int(x) for x in member_counts]
+            if len(widths) != world or widths[rank] != e_local:
+                raise ValueError("member_counts %s do not describe rank %d of %d holding %d members" % (widths, rank, world, e_local))
+        elif world > 1:
             sizes = [None] * world
             dist.all_gather_object(sizes, e_local, group=group)
             widths = [int(x) for x in sizes]

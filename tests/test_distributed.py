@@ -51,6 +51,21 @@ def _worker(rank, world, port, E, ret):
                                          m['up_ptr'], m['up_idx'], m['opts'])
         # members are independent: this rank's block is bit-identical to the same members of the unsharded run
         ok = res['out'].shape[-1] == hi - lo and bool(torch.equal(res['out'], full[..., lo:hi]))
+        # weak scaling: every rank brings its own block; block sizes exchanged by run_sharded, or handed in by the caller
+        counts = [b - a for a, b in (ensemble.shard_bounds(E, world, r) for r in range(world))]
+        for mc in (None, counts):
+            weak = ensemble.run_sharded(_oracle_run_fn, m['forcing'], m['doy'], np.ascontiguousarray(m['member_params'][:, lo:hi]),
+                                        np.ascontiguousarray(m['reach_params'][:, :, lo:hi]), m['up_ptr'], m['up_idx'], m['opts'],
+                                        sharded_inputs=True, total_members=E, member_counts=mc)
+            ok = ok and weak['bounds'] == (lo, hi) and bool(torch.equal(weak['out'], res['out']))
+            ok = ok and (rank != 0 or (bool(torch.equal(weak['summaries'], res['summaries'])) and bool(torch.equal(weak['all_status'], res['all_status']))))
+        try:
+            ensemble.run_sharded(_oracle_run_fn, m['forcing'], m['doy'], np.ascontiguousarray(m['member_params'][:, lo:hi]),
+                                 np.ascontiguousarray(m['reach_params'][:, :, lo:hi]), m['up_ptr'], m['up_idx'], m['opts'],
+                                 sharded_inputs=True, member_counts=[c + 1 for c in counts])
+            ok = False
+        except ValueError:
+            pass
         if rank == 0:
             want = ensemble.member_summaries(full)        # (a day-sum: reduction order may differ in the last bits)
             ok = ok and bool(torch.allclose(res['summaries'], want, rtol=1e-13, atol=0.0)) \
