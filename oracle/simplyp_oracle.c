@@ -261,6 +261,9 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
 #define NZ 15
 #define AUG_RESYNC 8
 #define AUG_NERR 7
+#define AUG_AUX_WEIGHT 3.0       /* SysAug::AUX_WEIGHT */
+#define AUG_KINK_SOIL 10.0       /* SysAug::KINK_SOIL: a step across a knee of a soil-water gate */
+#define AUG_KINK_GW 100.0        /* SysAug::KINK_GW: across a knee of the groundwater gate (zone 1 % of Qg_min wide) */
 static void ode_aug(const double* z, const ode_params* p, double invKv, double* dz)
 {
     double VsA = z[0], VsS = z[1], Vg = z[2], Qr = z[3], Msus = z[4], TDPr = z[5], PPr = z[6];
@@ -330,16 +333,41 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
             ode_aug(zt, p, invKv, k[s]);
         }
         st->rhs += 6;
-        double err = 0.0; int bad = 0;
+        double err = 0.0; int bad = 0, kink = 0, kink_gw = 0;
         for (int i = 0; i < NZ; ++i) {
             double inc = 0.0, ee = 0.0;
             for (int s = 0; s < 6; ++s) { inc += CK_B[s] * k[s][i]; ee += CK_E[s] * k[s][i]; }
             zn[i] = z[i] + hh * inc;
-            if (i >= AUG_NERR) continue;          /* error norm: the 7 physical states only (see below) */
-            double sc = atol + rtol * fmax(fabs(z[i]), fabs(z[i] + hh * k[0][i]));      /* Euler predictor, as in the kernel */
+            /* error norm: the 7 physical states (see below), and Qr**k_M (z[10]) at AUG_AUX_WEIGHT x the tolerance: on a day
+             * when a nearly dry reach is wetted it grows 200-fold, and its own truncation error then showed in the sediment
+             * flux (SysAug::AUX_WEIGHT in simplyp_kernels.hip.h) */
+            if (i >= AUG_NERR && i != 10) continue;
+            /* Error scale: rtol * max(|z|, |Euler predictor|) + atol, as in the kernel -- with the two soil boxes measured from
+             * field capacity and floored by the gate width 0.01 fc: what the rest of the system sees of a soil box is
+             * Vs - fc (gate argument and flow, model.py:105-110), ~1 mm out of ~300, so an error of 1e-8 |Vs| would be
+             * 3e-6 of the flow.  (SysAug::SOIL_REL in simplyp_kernels.hip.h.) */
+            const double dgate = 0.01 * p->fc;
+            double ref = (i < 2) ? z[i] - p->fc : z[i];
+            double pred = ref + hh * k[0][i];
+            double w = fmax(fabs(ref), fabs(pred));
+            if (i < 2) w = fmax(w, dgate);
+            double sc = atol + rtol * w;
+            if (i == 10) sc = AUG_AUX_WEIGHT * atol + (AUG_AUX_WEIGHT * rtol) * w;
             double r = fabs(hh * ee) / sc;
             if (r > err) err = r;
+            /* Steps across a knee of a gate (SysAug::KINK_AWARE): f_x (model.py:23-37) is C1 only, so where a soil box crosses
+             * fc or 1.01 fc, or Vg / T_g crosses Qg_min or 1.01 Qg_min, the pair drops to third order and its embedded estimate
+             * no longer bounds the error.  Start and Euler-predicted end on different sides of a knee <=> sign bits differ. */
+            if (i < 2)
+                kink |= (signbit(ref) != signbit(pred)) | (signbit(ref - dgate) != signbit(pred - dgate));
+            if (i == 2) {
+                const double invTg = 1.0 / p->T_g, dgq = 0.01 * p->Qg_min;
+                const double ug = ref * invTg - p->Qg_min, up = pred * invTg - p->Qg_min;
+                kink_gw = (signbit(ug) != signbit(up)) | (signbit(ug - dgq) != signbit(up - dgq));
+            }
         }
+        if (kink_gw) err *= AUG_KINK_GW;        /* such a step is accepted only if it is short */
+        else if (kink) err *= AUG_KINK_SOIL;
         if (!(err < 1.0e300)) bad = 1;
         for (int i = 0; i < 11; ++i) if (!(fabs(zn[i]) < 1.0e300)) bad = 1;
         ++attempts;
@@ -392,7 +420,7 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
  */
 typedef struct {
     float c0, aE, mu, fc, inv_d, invTsA, invTsS, invTg, Qgmin, inv_dg, beta, fA, fS, qin, omb, cQ, bQ, kM,
-          Esum, MsusUS, tA, tS, tg, tconst, cPP, PPrUS, invKv;
+          Esum, MsusUS, tA, tS, tg, tconst, cPP, PPrUS, invKv, dgate, dgq;
 } dayconst_f;
 
 static float gate_f(float u, float inv_d)            /* f_x as one clamped cubic, like the kernel's gate() */
@@ -434,6 +462,8 @@ static void dayconst_from_params(const ode_params* p, dayconst_f* c)
                                 + p->f_S * p->Esus_S * ((1 - p->f_NC_S) * p0 + p->f_NC_S * pN)));
     c->PPrUS = (float)p->PPr_US_i;
     c->invKv = (float)(1.0 / Kv);
+    c->dgate = (float)(0.01 * p->fc);
+    c->dgq = (float)(0.01 * p->Qg_min);
 }
 
 /* SysAugF::f, operation for operation.  z[11] = VsA VsS Vg Qr Msus TDPr PPr EA ES pb pk; q[4] = integrands of the
@@ -512,13 +542,27 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
         st->rhs += 6;
         float err = 0.0f, chk = 0.0f;
         const float he[6] = {hh * Ee[0], 0.0f, hh * Ee[2], hh * Ee[3], hh * Ee[4], hh * Ee[5]};
-        for (int i = 0; i < AUG_NERR; ++i) {
+        int kink = 0, kink_gw = 0;
+        for (int i = 0; i < NS; ++i) {
+            if (i >= AUG_NERR && i != 10) continue;       /* the 7 physical states + Qr**k_M, as in cashkarp_aug_day */
             const float e = fmaf(he[0], k[0][i], fmaf(he[2], k[2][i], fmaf(he[3], k[3][i], fmaf(he[4], k[4][i], he[5] * k[5][i]))));
-            if (i >= 3) chk += e;
-            const float sc = fmaf(rtol, fmaxf(fabsf(z[i]), fabsf(fmaf(hh, k[0][i], z[i]))), atol);
+            if (i >= 3 && i < AUG_NERR) chk += e;
+            const float ref = (i < 2) ? z[i] - c.fc : z[i];
+            const float pred = fmaf(hh, k[0][i], ref);
+            float w = fmaxf(fabsf(ref), fabsf(pred));
+            if (i < 2) w = fmaxf(w, c.dgate);
+            const float sc = (i == 10) ? fmaf((float)AUG_AUX_WEIGHT * rtol, w, (float)AUG_AUX_WEIGHT * atol) : fmaf(rtol, w, atol);
             const float r = fabsf(e) * (1.0f / sc);
             if (r > err) err = r;
+            if (i < 2)
+                kink |= (signbit(ref) != signbit(pred)) | (signbit(ref - c.dgate) != signbit(pred - c.dgate));
+            if (i == 2) {
+                const float ug = fmaf(ref, c.invTg, -c.Qgmin), up = fmaf(pred, c.invTg, -c.Qgmin);
+                kink_gw = (signbit(ug) != signbit(up)) | (signbit(ug - c.dgq) != signbit(up - c.dgq));
+            }
         }
+        if (kink_gw) err *= (float)AUG_KINK_GW;
+        else if (kink) err *= (float)AUG_KINK_SOIL;
         const int bad = !(err < 1.0e30f) || !(fabsf(chk) < 1.0e30f);
         ++attempts;
         if (last_chance) st->capped = 1;

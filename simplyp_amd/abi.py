@@ -68,8 +68,10 @@ GOF_STATS = ['N obs', 'NSE', 'log NSE', 'r2', 'Bias (%)', 'nRMSD (%)', 'sum_log_
 
 # Solver settings used when the caller does not choose: Cash-Karp 5(4) with per-thread step
 # control on the augmented (transcendental-free) form of the system, at the tolerance that meets
-# the <= 1e-6 parity bar against odeint(rtol=atol=1e-12) with a 10x margin.
-DEFAULT_SOLVER = dict(integrator='cashkarp_aug', substeps=8, rtol=1e-8, atol=1e-12, max_steps=4000, project_vr=1,
+# the <= 1e-6 parity bar against odeint(rtol=atol=1e-12) on every member of a 100 000-member Monte-Carlo
+# ensemble with a margin (1e-8 before the step controller learned about the knees
+# of the gates, round 2).
+DEFAULT_SOLVER = dict(integrator='cashkarp_aug', substeps=8, rtol=1e-7, atol=1e-12, max_steps=4000, project_vr=1,
                       balance=2, balance_pilot_days=0, out_slot_order=0, time_chunk_days=0, lanes_per_wave=0, lanes_per_member=0)
 
 

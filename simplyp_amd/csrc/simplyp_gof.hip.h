@@ -256,17 +256,14 @@ __device__ __forceinline__ double spearman_sim_value(const SpearmanArgs& g, int 
 {
     const size_t off = ((size_t)d * g.R + g.r) * g.E + slot;
     const double qr = g.out[(size_t)g.col[0] * g.col_stride + off];
-    if (g.var == SIMPLYP_GOF_Q) return g.a_catch ? qr * (A * 1000 / 86400) : qr;
+    // The reference's expressions operation for operation (model.py:784, :788-790), not the reciprocal forms of gof_chem_day: a
+    // rank statistic depends on which near-equal values tie, and on a long low-flow recession hundreds of daily values differ
+    // in their last bits only -- a differently rounded unit conversion collapses other pairs (seen: 7e-8 in r for one member).
+    if (g.var == SIMPLYP_GOF_Q) return g.a_catch ? qr * A * 1000 / 86400 : qr;
     const double ms = g.out[(size_t)g.col[1] * g.col_stride + off];
     const double td = g.out[(size_t)g.col[2] * g.col_stride + off];
     const double pp = g.out[(size_t)g.col[3] * g.col_stride + off];
-    double SS, TDP, PP;
-    if (qr > 1e-290 && qr < 1e290) {          // the same expressions as gof_chem_day
-        const double inv = sp_rcp(qr * A);
-        SS = ms * inv; TDP = td * inv; PP = pp * inv;
-    } else {
-        SS = (ms / qr) / A; TDP = (td / qr) / A; PP = (pp / qr) / A;
-    }
+    const double SS = (ms / qr) / A, TDP = (td / qr) / A, PP = (pp / qr) / A;
     switch (g.var) {
         case SIMPLYP_GOF_SS: return SS;
         case SIMPLYP_GOF_TDP: return TDP;

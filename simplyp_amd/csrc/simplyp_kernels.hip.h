@@ -197,6 +197,8 @@ struct DayConst {
     double s0;          // -fc inv_d:   (Vs - fc) inv_d = fma(Vs, inv_d, s0)
     double c0m;         // c0 - aE:     c0 + aE (E - 1) = fma(aE, E, c0m)
     double invKvc;      // invKv / cQ:  the state carried for Qr**b_Q is cQ Qr**b_Q, so dQr = inflow * state and Qr/Vr = state * invKvc
+    double dgate;       // 0.01 fc: width of the soil-water gate (model.py:35), floor of the soil boxes' error scale (SysAug)
+    double dgq;         // 0.01 Qg_min: width of the groundwater gate (:121); 0 when Qg_min is 0 (a plain step at 0)
 };
 
 // f_x(x, threshold, 0.01) with u = x - threshold and inv_d = 1/(0.01 threshold) (model.py:23-37):
@@ -288,6 +290,9 @@ __device__ __forceinline__ double sp_abs(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ float sp_abs(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ double sp_rcp_fast(double a) { return __builtin_amdgcn_rcp(a); }     // error-norm scale only
 __device__ __forceinline__ float sp_rcp_fast(float a) { return __builtin_amdgcn_rcpf(a); }
+// sign bits of a and b differ <=> the result is negative (one 32-bit xor on the high words)
+__device__ __forceinline__ int sp_sign_xor(double a, double b) { return __double2hiint(a) ^ __double2hiint(b); }
+__device__ __forceinline__ int sp_sign_xor(float a, float b) { return __float_as_int(a) ^ __float_as_int(b); }
 template <typename R> __device__ __forceinline__ R sp_huge();
 template <> __device__ __forceinline__ double sp_huge<double>() { return 1.0e300; }
 template <> __device__ __forceinline__ float sp_huge<float>() { return 1.0e30f; }
@@ -303,6 +308,8 @@ struct SysLiteral {
     static constexpr int RESYNC_EVERY = 0;
     static constexpr int N_ERR = 8;             // all 8 states and the 4 daily integrals enter the error norm
     static constexpr bool QUAD_IN_NORM = true;
+    static constexpr bool SOIL_REL = false;
+    static constexpr bool KINK_AWARE = false;
     static __device__ __forceinline__ void resync(double (&)[8], const DayConst&) {}
     static __device__ __forceinline__ void f(const double (&y)[8], const DayConst& c, double (&dy)[8], double (&q)[4])
     {
@@ -322,6 +329,27 @@ struct SysAug {
     // quadratures of them; see oracle/simplyp_oracle.c)
     static constexpr int N_ERR = 7;
     static constexpr bool QUAD_IN_NORM = false;
+    // Error scale of the two soil boxes: rtol * max(|Vs - fc|, 0.01 fc) instead of rtol * |Vs|.  Everything downstream sees a
+    // soil box through Vs - fc (the gate argument and the flow (Vs - fc)/T_s, model.py:105-110), a difference of ~1 mm between
+    // numbers of ~300 mm: an error that is 1e-8 of Vs is 3e-6 of the flow.  Mostly the soil boxes do not limit the step and
+    // their error stays far below their tolerance -- but a step that straddles a knee of the gate (C1 only) uses the tolerance
+    // up, and the flow error then shows in every reach output (worst member-day of 12 288 Monte-Carlo members at rtol 2e-8:
+    // 9.0e-7 in the TDP flux before, 2.7e-7 after; profiles/r02_experiments.md).  Costs no steps: see there.
+    static constexpr bool SOIL_REL = true;
+    // Steps across a knee of a gate.  f_x (model.py:23-37) is C1 only: where a soil box crosses fc or 1.01 fc, or Vg / T_g crosses
+    // Qg_min or 1.01 Qg_min, the second derivative of the right-hand side jumps, a 5(4) pair drops to third order on the step
+    // that straddles the knee and its embedded estimate no longer bounds the error (measured: the worst member-days of the
+    // 100 000-member bench ensemble were all such steps, 50 x above their tolerance).  A step whose start and Euler-predicted end
+    // lie on different sides of a knee therefore has its error estimate multiplied by KINK_SOIL / KINK_GW: it is accepted only if it is
+    // short.  With this, and Qr**k_M in the norm at AUX_WEIGHT x the tolerance (on a day when a nearly dry reach is wetted
+    // Qr**k_M grows 200-fold and its own truncation error showed in the sediment flux), the error at a given rtol drops 7-fold:
+    // rtol 1e-7 now gives what 1e-8 gave -- 90 instead of 126 right-hand sides per day (profiles/r02_experiments.md).
+    // (KINK_SOIL for the knees of the two soil-water gates, crossed on most wet days; KINK_GW for the groundwater gate, whose
+    // zone is 1 % of Qg_min wide and is crossed a few times a year by members with a low Qg_min: with 10 there, 7 members of
+    // the 100 000 still had a day at 5-9e-7)
+    static constexpr bool KINK_AWARE = true;
+    static constexpr double KINK_SOIL = 10.0, KINK_GW = 100.0;
+    static constexpr double AUX_WEIGHT = 3.0;
     // z[9] carries cQ * Qr**b_Q (the factor the flow equation multiplies it with, folded into the state: one multiplication
     // less per right-hand side; its ODE is linear in it, so the scaling changes nothing else)
     static __device__ __forceinline__ void resync(double (&z)[11], const DayConst& c)
@@ -374,14 +402,15 @@ struct SysAug {
 // stays fp64.
 struct DayConstF {
     float c0, aE, mu, fc, inv_d, invTsA, invTsS, invTg, Qgmin, inv_dg, beta, fA, fS, qin, omb, cQ, bQ, kM,
-          Esum, MsusUS, tA, tS, tg, tconst, cPP, PPrUS, invKv;
+          Esum, MsusUS, tA, tS, tg, tconst, cPP, PPrUS, invKv, dgate, dgq;
     __device__ __forceinline__ explicit DayConstF(const DayConst& c)
         : c0((float)c.c0), aE((float)c.aE), mu((float)c.mu), fc((float)c.fc), inv_d((float)c.inv_d),
           invTsA((float)c.invTsA), invTsS((float)c.invTsS), invTg((float)c.invTg), Qgmin((float)c.Qgmin),
           inv_dg((float)__builtin_fmin(c.inv_dg, 1.0e30)), beta((float)c.beta), fA((float)c.fA), fS((float)c.fS),
           qin((float)c.qin), omb((float)c.omb), cQ((float)c.cQ), bQ((float)c.bQ), kM((float)c.kM),
           Esum((float)c.Esum), MsusUS((float)c.MsusUS), tA((float)c.tA), tS((float)c.tS), tg((float)c.tg),
-          tconst((float)c.tconst), cPP((float)c.cPP), PPrUS((float)c.PPrUS), invKv((float)c.invKv) {}
+          tconst((float)c.tconst), cPP((float)c.cPP), PPrUS((float)c.PPrUS), invKv((float)c.invKv),
+          dgate((float)c.dgate), dgq((float)c.dgq) {}
 };
 
 __device__ __forceinline__ float gate(float u, float inv_d)
@@ -398,6 +427,11 @@ struct SysAugF {
     static constexpr int RESYNC_EVERY = 8;
     static constexpr int N_ERR = 7;
     static constexpr bool QUAD_IN_NORM = false;
+    // the step controller of SysAug, in float
+    static constexpr bool SOIL_REL = true;
+    static constexpr bool KINK_AWARE = true;
+    static constexpr double KINK_SOIL = SysAug::KINK_SOIL, KINK_GW = SysAug::KINK_GW;
+    static constexpr double AUX_WEIGHT = SysAug::AUX_WEIGHT;
     static __device__ __forceinline__ void resync(float (&z)[11], const DayConstF& c)
     {
         const float lq = __logf(z[3]);
@@ -448,6 +482,8 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     typedef typename SYS::real R;       // working precision of the stages (the daily integrals yq stay fp64)
     constexpr int NS = SYS::NS;
     const R T = (R)T_, rtol = (R)rtol_, atol = (R)atol_;
+    R rtol_aux = rtol, atol_aux = atol;
+    if constexpr (SYS::KINK_AWARE) { rtol_aux = (R)SYS::AUX_WEIGHT * rtol; atol_aux = (R)SYS::AUX_WEIGHT * atol; }
     R a21 = 1.0 / 5;
     R a31 = 3.0 / 40, a32 = 9.0 / 40;
     R a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
@@ -558,6 +594,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         // embedded error estimate and scaled error norm.  The scale uses the Euler predictor y + h k1 for "the new value":
         // the 5th-order increment itself is only formed once the step is accepted (weights premultiplied by the accept mask).
         R err = 0, chk = 0;
+        int kink = 0, kink_gw = 0;               // sign bit set: the step crosses a knee of a soil / the groundwater gate (SYS::KINK_AWARE)
         R dq[4];
         const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
 #pragma unroll
@@ -566,9 +603,29 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 const R he = sp_fma(he1, k1[i], sp_fma(he3, k3[i], sp_fma(he4, k4[i],
                                   sp_fma(he5, k5[i], he6 * k6[i]))));
                 if (i >= NS - (NS == 11 ? 8 : 4) && i < NS - (NS == 11 ? 4 : 0)) chk += he;
-                const R sc = sp_fma(rtol, sp_absmax(y[i], sp_fma(hh, k1[i], y[i])), atol);
+                R ref = y[i];
+                if constexpr (SYS::SOIL_REL) { if (i < 2) ref = y[i] - c.fc; }          // soil boxes: distance from field capacity
+                const R pred = sp_fma(hh, k1[i], ref);                                  // Euler predictor of the step's end
+                R w = sp_absmax(ref, pred);
+                if constexpr (SYS::SOIL_REL) { if (i < 2) w = sp_max(w, c.dgate); }
+                const R sc = sp_fma(rtol, w, atol);
                 err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
+                if constexpr (SYS::KINK_AWARE) {
+                    // start and predicted end on different sides of a knee of the gate <=> the sign bits differ
+                    if (i < 2) kink |= sp_sign_xor(ref, pred) | sp_sign_xor(ref - c.dgate, pred - c.dgate);
+                    if (i == 2) {
+                        const R ug = sp_fma(ref, c.invTg, -c.Qgmin), up = sp_fma(pred, c.invTg, -c.Qgmin);
+                        kink_gw = sp_sign_xor(ug, up) | sp_sign_xor(ug - c.dgq, up - c.dgq);
+                    }
+                }
             }
+        }
+        if constexpr (SYS::KINK_AWARE) {
+            // Qr**k_M (z[10]) in the norm, at AUX_WEIGHT x the tolerance
+            const R he = sp_fma(he1, k1[10], sp_fma(he3, k3[10], sp_fma(he4, k4[10], sp_fma(he5, k5[10], he6 * k6[10]))));
+            const R sc = sp_fma(rtol_aux, sp_absmax(y[10], sp_fma(hh, k1[10], y[10])), atol_aux);
+            err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
+            err *= (kink_gw < 0) ? (R)SYS::KINK_GW : ((kink < 0) ? (R)SYS::KINK_SOIL : (R)1);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -693,6 +750,14 @@ struct QuadConst {
     double c1;
     // slot-2 derivative:  d2 = fma(mK, pk, fma(mA, QsA, fma(mS, QsS, fma(mG, Qg, m4)))) - x2 kap
     double mG, m4, mS, mA, mK;
+    // error scale of slot 0: rtol * max(|x0 - eoff|, efloor) -- the soil lanes measure from field capacity (SysAug::SOIL_REL);
+    // 0 / 0 on the other lanes, where x - 0 and max(., 0) change nothing
+    double eoff, efloor;
+    // gate argument of slot 0 for the knee test (SysAug::KINK_AWARE): g = fma(x0 - eoff, gs, g0), knees at 0 and gd.  Soil lanes:
+    // the identity (gs = 1, g0 = -0.0) on Vs - fc, gd = 0.01 fc; groundwater lane: Vg / T_g - Qg_min, gd = 0.01 Qg_min; reach
+    // lane: constant 1 (no gate).  auxm: 1 on the lane whose slot 1 is Qr**k_M (in the norm at AUX_WEIGHT x the tolerance), else 0
+    double gs, g0, gd, auxm;
+    float kfac;          // factor on the error estimate of a step that crosses a knee of this lane's gate (KINK_SOIL / KINK_GW / 1)
     // the same for every lane
     double fA, fS, invKvc;
 };
@@ -723,6 +788,13 @@ __device__ __forceinline__ QuadConst quad_const(const DayConst& c, int j)
     k.mS = sel4(j, 0.0, c.tS, 0.0, 0.0);
     k.mA = sel4(j, 0.0, c.tA, 0.0, 0.0);
     k.mK = sel4(j, c.Esum, 0.0, c.cPP, 0.0);
+    k.eoff = sel4(j, c.fc, c.fc, 0.0, 0.0);
+    k.efloor = sel4(j, c.dgate, c.dgate, 0.0, 0.0);
+    k.gs = sel4(j, 1.0, 1.0, c.invTg, 0.0);
+    k.g0 = sel4(j, -0.0, -0.0, -c.Qgmin, 1.0);
+    k.gd = sel4(j, c.dgate, c.dgate, c.dgq, 0.0);
+    k.auxm = sel4(j, 0.0, 0.0, 1.0, 0.0);
+    k.kfac = (float)sel4(j, SysAug::KINK_SOIL, SysAug::KINK_SOIL, SysAug::KINK_GW, 1.0);
     k.fA = c.fA; k.fS = c.fS; k.invKvc = c.invKvc;
     return k;
 }
@@ -765,6 +837,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
     typedef double R;
     const bool j_lt2 = j < 2, j_eq2 = j == 2, j_eq3 = j == 3;
     const QuadConst k = quad_const(c, j);
+    const R rtol_aux = SysAug::AUX_WEIGHT * rtol, atol_aux = SysAug::AUX_WEIGHT * atol;
     R a21 = 1.0 / 5;
     R a31 = 3.0 / 40, a32 = 9.0 / 40;
     R a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
@@ -863,13 +936,29 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         // states (Qr, Msus, TDPr, PPr), as ck_day<SysAug>'s `chk` does: a non-finite one makes the lane's error infinite.
         const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
         R err = 0;
+        int kink = 0;
         R he_s[3];
 #pragma unroll
         for (int i = 0; i < 3; i += 2) {
             const R he = sp_fma(he1, k1[i], sp_fma(he3, k3[i], sp_fma(he4, k4[i], sp_fma(he5, k5[i], he6 * k6[i]))));
             he_s[i] = he;
-            const R sc = sp_fma(rtol, sp_absmax(y[i], sp_fma(hh, k1[i], y[i])), atol);
+            // slot 0 of the soil lanes is measured from field capacity, like ck_day<SysAug> does for components 0 and 1
+            const R ref = (i == 0) ? y[0] - k.eoff : y[i];
+            const R pred = sp_fma(hh, k1[i], ref);
+            R w = sp_absmax(ref, pred);
+            if (i == 0) w = sp_max(w, k.efloor);
+            const R sc = sp_fma(rtol, w, atol);
             err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
+            if (i == 0) {      // knee test of this lane's gate, as ck_day<SysAug> does for components 0, 1, 2
+                const R g = sp_fma(ref, k.gs, k.g0), gp = sp_fma(pred, k.gs, k.g0);
+                kink = sp_sign_xor(g, gp) | sp_sign_xor(g - k.gd, gp - k.gd);
+            }
+        }
+        {
+            // Qr**k_M (slot 1 of the groundwater lane) in the norm at AUX_WEIGHT x the tolerance; x 0 on the other lanes
+            const R he = sp_fma(he1, k1[1], sp_fma(he3, k3[1], sp_fma(he4, k4[1], sp_fma(he5, k5[1], he6 * k6[1]))));
+            const R sc = sp_fma(rtol_aux, sp_absmax(y[1], sp_fma(hh, k1[1], y[1])), atol_aux);
+            err = sp_max(err, (sp_abs(he) * sp_rcp_fast(sc)) * k.auxm);
         }
         {
             const R chk = j_eq3 ? he_s[0] : he_s[2];
@@ -877,6 +966,13 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         }
         err = sp_max(err, quad_perm<SP_QP(1, 0, 3, 2)>(err));
         err = sp_max(err, quad_perm<SP_QP(2, 3, 0, 1)>(err));
+        {
+            // the largest factor any lane of the quad asks for (KINK_GW > KINK_SOIL > 1: the one-lane kernel's choice)
+            float kf = (kink < 0) ? k.kfac : 1.0f;
+            kf = fmaxf(kf, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kf), SP_QP(1, 0, 3, 2), 0xf, 0xf, true)));
+            kf = fmaxf(kf, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kf), SP_QP(2, 3, 0, 1), 0xf, 0xf, true)));
+            err *= (double)kf;
+        }
         R dq = hh * sq;
         const bool bad = !(err < huge);
 
@@ -1076,6 +1172,8 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
         c.invKv = 1.0 / Kv;
         c.wA0 = -fc * c.invTsA; c.wS0 = -fc * c.invTsS; c.s0 = -fc * c.inv_d;
         c.invKvc = c.invKv / c.cQ;
+        c.dgate = 0.01 * fc;
+        c.dgq = 0.01 * Qg_min;
 
         const double slopeA = RPv(SIMPLYP_PR_S_AR, s), slopeIG = RPv(SIMPLYP_PR_S_IG, s), slopeS = RPv(SIMPLYP_PR_S_SN, s);
         const double ES = MPv(SIMPLYP_PM_E_M) * RPv(SIMPLYP_PR_S_REACH, s);

@@ -112,3 +112,13 @@ def gof_case_factors(index):
     return {'base': dict(Q=1.0, C=1.0),
             'wet': dict(Q=1.25 + 0.1 * np.sin(2 * np.pi * t), C=0.8),
             'dry': dict(Q=0.7, C=1.4 + 0.3 * np.cos(2 * np.pi * t / 3.0))}
+
+
+# Two valid integrations at the default solver's working tolerance (kernel and oracle mirror the same step rule, but an
+# accept/reject decision may flip on rounding) agree to about ten times that tolerance.
+def _working_tolerance():
+    from simplyp_amd import abi
+    return 10.0 * abi.DEFAULT_SOLVER['rtol']
+
+
+TOL_WORKING = _working_tolerance()

@@ -60,8 +60,8 @@ def test_native_library_is_the_one_running(engine0):
     (dict(integrator='cashkarp', rtol=1e-11, atol=1e-13), 1e-9),
     (dict(integrator='cashkarp_aug', rtol=1e-11, atol=1e-13), 1e-9),
     # adaptive at working tolerances: both are valid integrations at rtol, they agree to ~10 rtol
-    (None, 1e-7),
-    (dict(integrator='cashkarp'), 1e-7),
+    (None, helpers.TOL_WORKING),
+    (dict(integrator='cashkarp'), helpers.TOL_WORKING),
     (dict(integrator='cashkarp_aug', rtol=1e-6, atol=1e-9), 1e-5),
     (dict(integrator='cashkarp', rtol=1e-6, atol=1e-9, project_vr=0), 1e-5)])
 def test_kernel_matches_oracle(engine0, oracle_lib, name, solver, tol):
@@ -287,7 +287,7 @@ def test_run_simply_p_ensemble_overrides(engine0, oracle_lib):
     m['member_params'][marshal.PM_NAMES.index('T_s_A')] = over['T_s_A']
     m['reach_params'][marshal.PR_NAMES.index('L_reach')] = over['L_reach']
     ref, _, _ = cpu_run(oracle_lib, m, out_reaches=[3])
-    assert helpers.max_rel_err(res['data'], ref, floor=FLOOR) < 1e-7
+    assert helpers.max_rel_err(res['data'], ref, floor=FLOOR) < helpers.TOL_WORKING
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -317,7 +317,7 @@ def test_full_size_monte_carlo_properties(engine0, oracle_lib):
     sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
     ref, _, _ = cpu_run(oracle_lib, sub, n_threads=8)
     got = out[..., torch.as_tensor(pick, device=out.device)].cpu().numpy()
-    assert helpers.max_rel_err(got, ref, floor=FLOOR) < 1e-7
+    assert helpers.max_rel_err(got, ref, floor=FLOOR) < helpers.TOL_WORKING
     # the working tolerance holds across the parameter distribution, not only for the golden members: every 16th member
     # (4375 of them), all 10 957 days, REACH-5 columns, against the same kernel at rtol 1e-11 -- which the golden
     # scenarios pin to the reference's tight solution to 1e-9 (test_kernel_matches_oracle / test_oracle_series)
@@ -381,7 +381,8 @@ def test_one_million_members_on_one_gpu(engine0):
 def test_load_balancer_groups_members_with_similar_step_patterns(engine0):
     """What the pilot + ordering is for: lanes of a wavefront that need similar step counts day by day.  On the bench's
     Monte-Carlo distribution the fraction of issued lane-attempts that were needed (stats.simt_efficiency) rises from
-    ~0.63 (members as drawn) to ~0.82; asserted with margin, on a 3-year slice."""
+    ~0.62 (members as drawn) to ~0.77 (0.82 before the step controller shortened the steps that cross a knee of a gate:
+    which lane crosses on which day is not something a pilot run can predict); asserted with margin, on a 3-year slice."""
     pr = synthetic.c3_problem(70000, end_dt='1983-12-31', solver=dict(out_slot_order=1))
     eff = {}
     for balance in (0, 1):
@@ -391,7 +392,7 @@ def test_load_balancer_groups_members_with_similar_step_patterns(engine0):
         eff[balance] = st['simt_efficiency']
         mos = st['member_of_slot'].cpu().numpy()
         assert sorted(mos.tolist()) == list(range(70000))
-    assert eff[0] < 0.70 and eff[1] > 0.78 and eff[1] - eff[0] > 0.12, eff
+    assert eff[0] < 0.70 and eff[1] > 0.74 and eff[1] - eff[0] > 0.12, eff
 
 
 @pytest.mark.parametrize('name', ['tarland_2004_dynamic', 'chain4_val_2004', 'confluence3_nc_2004'])
@@ -434,7 +435,7 @@ def test_c4_chain_of_256_reaches_in_kernel(engine0, oracle_lib):
     sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
     ref, rstatus, _ = cpu_run(oracle_lib, sub, out_reaches=pr['out_reaches'], n_threads=3)
     assert rstatus.max() == 0
-    assert helpers.max_rel_err(got[..., pick], ref, floor=FLOOR) < 1e-7
+    assert helpers.max_rel_err(got[..., pick], ref, floor=FLOOR) < helpers.TOL_WORKING
     # flow accumulates down the chain: the outlet carries far more water per unit of its own area than a headwater
     assert got[1].mean() > 5.0
 
@@ -560,7 +561,7 @@ def test_c4_chain_pipelined_matches_chain_kernel_and_oracle(engine0, oracle_lib)
     pick = [5, 64]
     sub = dict(pr, member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
     cref, _, _ = cpu_run(oracle_lib, sub, out_reaches=pr['out_reaches'], n_threads=2)
-    assert helpers.max_rel_err(out.cpu().numpy()[..., pick], cref, floor=FLOOR) < 1e-7
+    assert helpers.max_rel_err(out.cpu().numpy()[..., pick], cref, floor=FLOOR) < helpers.TOL_WORKING
 
 
 @pytest.mark.parametrize('name', ['tarland_1981_2010_dynamic', 'confluence3_nc_2004'])
@@ -568,8 +569,10 @@ def test_fp32_stage_mode(engine0, name):
     """BASELINE config C5's arithmetic: the Runge-Kutta stages in fp32, the four daily integrals (Qr, Msus/TDP/PP
     kg/day), the soil-P update and everything carried from day to day outside the stages in fp64.  Tolerance: 5e-4
     relative on every reach output against the reference at rtol=atol=1e-12, with rtol 1e-5 / atol 1e-7 -- the same
-    error the fp64 scheme has at that tolerance (both asserted), i.e. the precision of the stages is not what limits
-    it.  fp32 cannot resolve rtol below ~3e-6; this mode is for screening ensembles, not for parity."""
+    class of error the fp64 scheme had at that tolerance before its controller learned about the knees of the gates (the
+    fp64 scheme now reaches 2e-5 there; fp32 stays at 1.6e-4: one float ulp of a soil store of 300 mm is 3e-5 mm, the
+    tolerance the soil boxes are now held to), with about as many right-hand-side evaluations (10 %).  fp32 cannot resolve
+    rtol below ~3e-6; this mode is for screening ensembles, not for parity."""
     solver = dict(rtol=1e-5, atol=1e-7)
     gold = helpers.golden_tables(name, 'tight')
     worst = {}
@@ -582,7 +585,7 @@ def test_fp32_stage_mode(engine0, name):
                            for j, sc in enumerate(m['scs']) for c in REACH_COLS)
         worst[integ + '_rhs'] = stats['rhs_evals']
     assert worst['cashkarp_aug_f32'] < 5e-4 and worst['cashkarp_aug'] < 5e-4, worst
-    assert abs(worst['cashkarp_aug_f32_rhs'] - worst['cashkarp_aug_rhs']) < 0.02 * worst['cashkarp_aug_rhs'], worst
+    assert abs(worst['cashkarp_aug_f32_rhs'] - worst['cashkarp_aug_rhs']) < 0.10 * worst['cashkarp_aug_rhs'], worst
 
 
 @pytest.mark.parametrize('name', ['tarland_2004_dynamic', 'tarland_1981_2010_dynamic', 'chain4_val_2004', 'confluence3_nc_2004'])
@@ -640,7 +643,7 @@ def test_random_reach_networks_match_the_oracle(engine0, oracle_lib, seed):
     for pname, lo, hi in (('fc', 0.9, 1.1), ('T_g', 0.7, 1.4), ('a_Q', 0.7, 1.5), ('E_M', 0.5, 2.0)):
         mp[marshal.PM_NAMES.index(pname)] *= rng.uniform(lo, hi, E)
     m = dict(base, member_params=mp, reach_params=rp, up_ptr=np.asarray(up_ptr, dtype=np.int32), up_idx=np.asarray(up_idx, dtype=np.int32))
-    for solver, tol in ((dict(integrator='rk4', substeps=96), 1e-9), (None, 1e-7)):      # (24 substeps are unstable on the big confluences)
+    for solver, tol in ((dict(integrator='rk4', substeps=96), 1e-9), (None, helpers.TOL_WORKING)):      # (24 substeps are unstable on the big confluences)
         m['opts'] = abi.make_opts(solver, dynamic_epc0=True, dynamic_erod=True, run_mode_cal=True, sc_qr0=S - 1, out_mask=marshal.MASK_ALL)
         ref, ref_status, _ = cpu_run(oracle_lib, m, n_threads=8)
         m['opts'].time_chunk_days = -1

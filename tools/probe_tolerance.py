@@ -1,6 +1,6 @@
 """Error of the working tolerances across the bench's Monte-Carlo ensemble: each member's max relative error over the
 REACH-5 daily columns (30 years) against the same kernel at rtol 1e-11 / atol 1e-13 (which the goldens pin to the
-reference's tight solution to 1e-9).  Usage: python tools/probe_tolerance.py [members]"""
+reference's tight solution to 1e-9).  Usage: python tools/probe_tolerance.py [members [rtol ...]]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,14 +20,15 @@ def run(solver):
 truth, st, _ = run(dict(rtol=1e-11, atol=1e-13))
 print('truth flagged', int((st != 0).sum()), flush=True)
 print('lib', engine.LIB_PATH)
-for rtol, atol in (((1e-8, 1e-12),) if E > 20000 else ((1e-8, 1e-12), (2e-8, 1e-12), (3e-8, 1e-12))):
+rtols = [float(x) for x in sys.argv[2:]] or ([1e-8] if E > 20000 else [1e-8, 2e-8, 3e-8])
+for rtol, atol in [(r, 1e-12) for r in rtols]:
     out, st, stats = run(dict(rtol=rtol, atol=atol))
     rel = (out - truth).abs_().div_(truth.abs().clamp_min(1e-300))
     per_member = rel.amax(dim=(0, 1, 2))                      # [E]
     per_col = rel.amax(dim=(1, 2, 3))
     q = torch.quantile(per_member.float(), torch.tensor([0.5, 0.99, 0.999], device=per_member.device))
-    print('rtol %.0e atol %.0e: rhs/day %.1f | member max-rel-err: median %.2e p99 %.2e p99.9 %.2e max %.2e | members > 1e-6: %d | per column %s'
-          % (rtol, atol, stats['rhs_evals'] / (E * out.shape[1]), q[0], q[1], q[2], per_member.max(), int((per_member > 1e-6).sum()),
+    print('rtol %.1e atol %.0e: rhs/day %.1f kernel %.1f ms | member max-rel-err: median %.2e p99 %.2e p99.9 %.2e max %.2e | members > 5e-7: %d > 1e-6: %d | per column %s'
+          % (rtol, atol, stats['rhs_evals'] / (E * out.shape[1]), stats['kernel_ms'], q[0], q[1], q[2], per_member.max(), int((per_member > 5e-7).sum()), int((per_member > 1e-6).sum()),
              ['%.1e' % v for v in per_col.tolist()]), flush=True)
     worst = int(per_member.argmax())
     flat = rel[..., worst].flatten().argmax()
