@@ -80,6 +80,7 @@ def parse_args(argv=None):
     ap.add_argument('--reaches', type=int, default=256, help='c4 only')
     ap.add_argument('--days', type=int, default=None, help='c4 only (default 18262)')
     ap.add_argument('--rtol', type=float, default=None, help='override the config\'s solver tolerance (experiments)')
+    ap.add_argument('--chunk-days', type=int, default=None, help='opts.time_chunk_days (experiments; default: the library chooses)')
     ap.add_argument('--no-stream', action='store_true', help='leave the output table in HBM (value = device-resident rate)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the accuracy checks (keeps a profile to one kernel shape)')
@@ -145,6 +146,8 @@ def build_problem(cfg, n_members, seed_offset, args):
         pr['period_of_day'] = np.ascontiguousarray(pod, dtype=np.int32)
     if args.rtol is not None:
         pr['opts'].rtol = args.rtol
+    if args.chunk_days is not None:
+        pr['opts'].time_chunk_days = args.chunk_days
     pr.setdefault('out_reaches', None)
     pr.setdefault('period_of_day', None)
     return pr
@@ -197,7 +200,10 @@ def main():
     ncols = bin(opts.out_mask).count('1')
     rows = opts.n_periods if opts.n_periods > 0 else D
 
-    numa_node = engine.bind_host_thread_to_gpu_numa_node(local_rank) if world > 1 else None      # staging buffers next to the GPU's PCIe root
+    # staging buffers next to the GPU's PCIe root: page-locked memory is placed by first touch, and a 44 GB buffer on the other
+    # socket costs a fifth of the D2H rate (44.8 instead of 55.9 GB/s: tools/probe_d2h_numa.py) -- also with one rank, which the
+    # scheduler may have started on either socket
+    numa_node = engine.bind_host_thread_to_gpu_numa_node(local_rank)
     eng = engine.get_engine(local_rank)
     # inputs: marshalled into pinned host arrays, uploaded once (resident in HBM before the timed region)
     pinned = {}

@@ -263,6 +263,7 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
 #define AUG_NERR 7
 #define AUG_AUX_WEIGHT 3.0       /* SysAug::AUX_WEIGHT */
 #define AUG_KINK_SOIL 10.0       /* SysAug::KINK_SOIL: a step across a knee of a soil-water gate */
+#define AUG_KINK_REACH 1.25      /* SysAug::KINK_REACH: the end of the step is looked for this far along the first slope */
 #define AUG_KINK_GW 100.0        /* SysAug::KINK_GW: across a knee of the groundwater gate (zone 1 % of Qg_min wide) */
 static void ode_aug(const double* z, const ode_params* p, double invKv, double* dz)
 {
@@ -358,12 +359,17 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
             /* Steps across a knee of a gate (SysAug::KINK_AWARE): f_x (model.py:23-37) is C1 only, so where a soil box crosses
              * fc or 1.01 fc, or Vg / T_g crosses Qg_min or 1.01 Qg_min, the pair drops to third order and its embedded estimate
              * no longer bounds the error.  Start and Euler-predicted end on different sides of a knee <=> sign bits differ. */
+            const double far = ref + (hh * AUG_KINK_REACH) * k[0][i];
             if (i < 2)
-                kink |= (signbit(ref) != signbit(pred)) | (signbit(ref - dgate) != signbit(pred - dgate));
+                kink |= (signbit(ref) != signbit(far)) | (signbit(ref - dgate) != signbit(far - dgate));
             if (i == 2) {
                 const double invTg = 1.0 / p->T_g, dgq = 0.01 * p->Qg_min;
-                const double ug = ref * invTg - p->Qg_min, up = pred * invTg - p->Qg_min;
+                const double ug = ref * invTg - p->Qg_min, up = far * invTg - p->Qg_min;
                 kink_gw = (signbit(ug) != signbit(up)) | (signbit(ug - dgq) != signbit(up - dgq));
+                /* a soil box that starts to drain within the step can lift Vg through its gate within the same step, which
+                 * the predictor (slope at the step's start: -Qg) cannot see: a step across a soil knee while Vg / T_g is
+                 * below the upper knee of its gate counts as crossing that too */
+                kink_gw |= kink & (signbit(ug - dgq) != 0);
             }
         }
         if (kink_gw) err *= AUG_KINK_GW;        /* such a step is accepted only if it is short */
@@ -554,11 +560,13 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
             const float sc = (i == 10) ? fmaf((float)AUG_AUX_WEIGHT * rtol, w, (float)AUG_AUX_WEIGHT * atol) : fmaf(rtol, w, atol);
             const float r = fabsf(e) * (1.0f / sc);
             if (r > err) err = r;
+            const float far = fmaf(hh * (float)AUG_KINK_REACH, k[0][i], ref);
             if (i < 2)
-                kink |= (signbit(ref) != signbit(pred)) | (signbit(ref - c.dgate) != signbit(pred - c.dgate));
+                kink |= (signbit(ref) != signbit(far)) | (signbit(ref - c.dgate) != signbit(far - c.dgate));
             if (i == 2) {
-                const float ug = fmaf(ref, c.invTg, -c.Qgmin), up = fmaf(pred, c.invTg, -c.Qgmin);
+                const float ug = fmaf(ref, c.invTg, -c.Qgmin), up = fmaf(far, c.invTg, -c.Qgmin);
                 kink_gw = (signbit(ug) != signbit(up)) | (signbit(ug - c.dgq) != signbit(up - c.dgq));
+                kink_gw |= kink & (signbit(ug - c.dgq) != 0);
             }
         }
         if (kink_gw) err *= (float)AUG_KINK_GW;

@@ -349,6 +349,7 @@ struct SysAug {
     // the 100 000 still had a day at 5-9e-7)
     static constexpr bool KINK_AWARE = true;
     static constexpr double KINK_SOIL = 10.0, KINK_GW = 100.0;
+    static constexpr double KINK_REACH = 1.25;
     static constexpr double AUX_WEIGHT = 3.0;
     // z[9] carries cQ * Qr**b_Q (the factor the flow equation multiplies it with, folded into the state: one multiplication
     // less per right-hand side; its ODE is linear in it, so the scaling changes nothing else)
@@ -430,7 +431,7 @@ struct SysAugF {
     // the step controller of SysAug, in float
     static constexpr bool SOIL_REL = true;
     static constexpr bool KINK_AWARE = true;
-    static constexpr double KINK_SOIL = SysAug::KINK_SOIL, KINK_GW = SysAug::KINK_GW;
+    static constexpr double KINK_SOIL = SysAug::KINK_SOIL, KINK_GW = SysAug::KINK_GW, KINK_REACH = SysAug::KINK_REACH;
     static constexpr double AUX_WEIGHT = SysAug::AUX_WEIGHT;
     static __device__ __forceinline__ void resync(float (&z)[11], const DayConstF& c)
     {
@@ -595,6 +596,8 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         // the 5th-order increment itself is only formed once the step is accepted (weights premultiplied by the accept mask).
         R err = 0, chk = 0;
         int kink = 0, kink_gw = 0;               // sign bit set: the step crosses a knee of a soil / the groundwater gate (SYS::KINK_AWARE)
+        R hfar = hh;
+        if constexpr (SYS::KINK_AWARE) hfar = hh * (R)SYS::KINK_REACH;
         R dq[4];
         const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
 #pragma unroll
@@ -611,11 +614,19 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 const R sc = sp_fma(rtol, w, atol);
                 err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
                 if constexpr (SYS::KINK_AWARE) {
-                    // start and predicted end on different sides of a knee of the gate <=> the sign bits differ
-                    if (i < 2) kink |= sp_sign_xor(ref, pred) | sp_sign_xor(ref - c.dgate, pred - c.dgate);
+                    // start and predicted end on different sides of a knee of the gate <=> the sign bits differ.  The end is
+                    // predicted KINK_REACH x the Euler displacement ahead: a step that, by its first slope, stops just short
+                    // of a knee may well cross it.
+                    const R far = sp_fma(hfar, k1[i], ref);
+                    if (i < 2) kink |= sp_sign_xor(ref, far) | sp_sign_xor(ref - c.dgate, far - c.dgate);
                     if (i == 2) {
-                        const R ug = sp_fma(ref, c.invTg, -c.Qgmin), up = sp_fma(pred, c.invTg, -c.Qgmin);
-                        kink_gw = sp_sign_xor(ug, up) | sp_sign_xor(ug - c.dgq, up - c.dgq);
+                        const R ug = sp_fma(ref, c.invTg, -c.Qgmin), up = sp_fma(far, c.invTg, -c.Qgmin);
+                        const R ugd = ug - c.dgq;
+                        kink_gw = sp_sign_xor(ug, up) | sp_sign_xor(ugd, up - c.dgq);
+                        // A soil box that starts to drain within the step can lift Vg through its gate within the same step,
+                        // which a predictor from the slope at the step's start (dVg/dt = -Qg there) cannot see: a step that
+                        // crosses a soil knee while Vg / T_g is below the upper knee of its gate counts as crossing that too.
+                        kink_gw |= kink & sp_sign_xor(ugd, (R)0);
                     }
                 }
             }
@@ -757,7 +768,8 @@ struct QuadConst {
     // the identity (gs = 1, g0 = -0.0) on Vs - fc, gd = 0.01 fc; groundwater lane: Vg / T_g - Qg_min, gd = 0.01 Qg_min; reach
     // lane: constant 1 (no gate).  auxm: 1 on the lane whose slot 1 is Qr**k_M (in the norm at AUX_WEIGHT x the tolerance), else 0
     double gs, g0, gd, auxm;
-    float kfac;          // factor on the error estimate of a step that crosses a knee of this lane's gate (KINK_SOIL / KINK_GW / 1)
+    int kbit, lowbit;    // what this lane reports to its quad: 1 = a soil knee crossed, 2 = a groundwater knee crossed (kbit);
+                         // 4 = Vg / T_g starts below the upper knee of its gate (lowbit, groundwater lane only)
     // the same for every lane
     double fA, fS, invKvc;
 };
@@ -794,7 +806,8 @@ __device__ __forceinline__ QuadConst quad_const(const DayConst& c, int j)
     k.g0 = sel4(j, -0.0, -0.0, -c.Qgmin, 1.0);
     k.gd = sel4(j, c.dgate, c.dgate, c.dgq, 0.0);
     k.auxm = sel4(j, 0.0, 0.0, 1.0, 0.0);
-    k.kfac = (float)sel4(j, SysAug::KINK_SOIL, SysAug::KINK_SOIL, SysAug::KINK_GW, 1.0);
+    k.kbit = j < 2 ? 1 : (j == 2 ? 2 : 0);
+    k.lowbit = j == 2 ? 4 : 0;
     k.fA = c.fA; k.fS = c.fS; k.invKvc = c.invKvc;
     return k;
 }
@@ -950,8 +963,9 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
             const R sc = sp_fma(rtol, w, atol);
             err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
             if (i == 0) {      // knee test of this lane's gate, as ck_day<SysAug> does for components 0, 1, 2
-                const R g = sp_fma(ref, k.gs, k.g0), gp = sp_fma(pred, k.gs, k.g0);
-                kink = sp_sign_xor(g, gp) | sp_sign_xor(g - k.gd, gp - k.gd);
+                const R g = sp_fma(ref, k.gs, k.g0), gp = sp_fma(sp_fma(hh * SysAug::KINK_REACH, k1[0], ref), k.gs, k.g0);
+                const R gd = g - k.gd;
+                kink = ((sp_sign_xor(g, gp) | sp_sign_xor(gd, gp - k.gd)) < 0 ? k.kbit : 0) | (sp_sign_xor(gd, (R)0) < 0 ? k.lowbit : 0);
             }
         }
         {
@@ -967,11 +981,11 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         err = sp_max(err, quad_perm<SP_QP(1, 0, 3, 2)>(err));
         err = sp_max(err, quad_perm<SP_QP(2, 3, 0, 1)>(err));
         {
-            // the largest factor any lane of the quad asks for (KINK_GW > KINK_SOIL > 1: the one-lane kernel's choice)
-            float kf = (kink < 0) ? k.kfac : 1.0f;
-            kf = fmaxf(kf, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kf), SP_QP(1, 0, 3, 2), 0xf, 0xf, true)));
-            kf = fmaxf(kf, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kf), SP_QP(2, 3, 0, 1), 0xf, 0xf, true)));
-            err *= (double)kf;
+            // what the lanes of the quad saw, OR-ed; then the one-lane kernel's choice of factor
+            kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(1, 0, 3, 2), 0xf, 0xf, true);
+            kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(2, 3, 0, 1), 0xf, 0xf, true);
+            const bool gw = (kink & 2) != 0 || (kink & 5) == 5;
+            err *= gw ? SysAug::KINK_GW : ((kink & 1) ? SysAug::KINK_SOIL : 1.0);
         }
         R dq = hh * sq;
         const bool bad = !(err < huge);

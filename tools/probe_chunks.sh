@@ -1,0 +1,17 @@
+#!/bin/bash
+# Streamed pass of the C3 bench against the copy granularity (opts.time_chunk_days), on whatever box this lands on.  Some boxes
+# stream 860 copies of 51 MB at 44.9 GB/s where others reach 55.9 (a plain 8 GB copy makes 57.1 on both): `quick` stops after
+# the first measurement on a fast box.     Usage: bash tools/probe_chunks.sh [quick]
+mkdir -p gpurun_out/r02s
+run() {
+  timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --chunk-days $1 > gpurun_out/r02s/bench_$1.json 2> gpurun_out/r02s/bench_$1.err
+  python -c "
+import json
+d=json.load(open('gpurun_out/r02s/bench_$1.json'))
+print('chunk_days', $1, 'ms/step %.1f kernel %.1f tail %.1f chunks %d d2h %.1f GB/s' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['transfer']['d2h_tail_ms'], d['transfer']['streamed_chunks'], d['transfer']['d2h_gbs_over_run']))
+open('gpurun_out/r02s/last_ms','w').write(str(int(d['ms_per_step'])))"
+}
+run 64
+if [ "$1" = quick ] && [ "$(cat gpurun_out/r02s/last_ms)" -lt 880 ]; then echo "fast box: nothing to learn here"; exit 0; fi
+for cd in 128 256 512 1024; do run $cd; done
+python tools/probe_d2h_numa.py 8
