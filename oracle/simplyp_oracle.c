@@ -264,6 +264,10 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
 #define AUG_AUX_WEIGHT 3.0       /* SysAug::AUX_WEIGHT */
 #define AUG_KINK_SOIL 10.0       /* SysAug::KINK_SOIL: a step across a knee of a soil-water gate */
 #define AUG_KINK_REACH 1.25      /* SysAug::KINK_REACH: the end of the step is looked for this far along the first slope */
+#define AUG_KNEE_LO 0.02         /* SysAug::KNEE_LO, KNEE_HI, KNEE_OVER: a knee between 2 % and 90 % of the step, along the */
+#define AUG_KNEE_HI 0.9          /* first slope, ends the step 5 % past the knee (no inflation for such a step)            */
+#define AUG_KNEE_OVER 1.05
+#define AUG_KNEE_GW 10.0          /* SysAug::KNEE_GW: a step aimed at a knee of the groundwater gate keeps this factor */
 #define AUG_KINK_GW 100.0        /* SysAug::KINK_GW: across a knee of the groundwater gate (zone 1 % of Qg_min wide) */
 static void ode_aug(const double* z, const ode_params* p, double invKv, double* dz)
 {
@@ -325,6 +329,22 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
         int last_chance = (attempts + 1 >= max_steps);
         if (last_chance) hh = rem;
         ode_aug(z, p, invKv, k[0]);
+        /* Aim at the knee (SysAug::KNEE_*): time to the nearest knee of a gate along the first slope; a knee inside the step
+         * ends the step just past it, so that the right-hand side is smooth over all but its last few percent. */
+        int targeted = 0;
+        {
+            double hk = 1.0e300;
+            const double tlo = AUG_KNEE_LO * hh, invTg = 1.0 / p->T_g;
+            for (int i = 0; i < 3; ++i) {
+                const double g = (i < 2) ? z[i] - p->fc : z[2] * invTg - p->Qg_min;
+                const double sl = (i < 2) ? k[0][i] : k[0][2] * invTg;
+                const double gd = (i < 2) ? 0.01 * p->fc : 0.01 * p->Qg_min;
+                const double t0 = (0.0 - g) / sl, t1 = (gd - g) / sl;
+                if (t0 > tlo && t0 < hk) hk = t0;
+                if (t1 > tlo && t1 < hk) hk = t1;
+            }
+            if (!last_chance && hk * AUG_KNEE_OVER < AUG_KNEE_HI * hh) { hh = hk * AUG_KNEE_OVER; targeted = 1; }
+        }
         for (int s = 1; s < 6; ++s) {
             for (int i = 0; i < NZ; ++i) {
                 double acc = 0.0;
@@ -372,8 +392,8 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
                 kink_gw |= kink & (signbit(ug - dgq) != 0);
             }
         }
-        if (kink_gw) err *= AUG_KINK_GW;        /* such a step is accepted only if it is short */
-        else if (kink) err *= AUG_KINK_SOIL;
+        if (kink_gw) err *= targeted ? AUG_KNEE_GW : AUG_KINK_GW;     /* a crossing the first slope did not announce: accepted only if short */
+        else if (kink && !targeted) err *= AUG_KINK_SOIL;            /* (a step that ends at a soil knee: no inflation) */
         if (!(err < 1.0e300)) bad = 1;
         for (int i = 0; i < 11; ++i) if (!(fabs(zn[i]) < 1.0e300)) bad = 1;
         ++attempts;
@@ -399,7 +419,8 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
         if (bad) fac = 0.2;
         else if (err == 0.0) fac = 5.0;
         else { fac = 0.9 * pow(err, -0.2); if (fac < 0.2) fac = 0.2; if (fac > 5.0) fac = 5.0; }
-        h = hh * fac;
+        /* (a step that was cut to end at a knee and accepted does not shorten the step size carried on) */
+        if (!(targeted && !bad && err <= 1.0 && hh * fac < h)) h = hh * fac;
     }
     *h_carry = h;
     y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[6] = z[4]; y[8] = z[5]; y[10] = z[6];
@@ -533,6 +554,22 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
         if (last_chance) hh = rem;
         ode_aug_f32(z, &c, k[0], kq);
         for (int i = 0; i < 4; ++i) sq[i] = B[0] * kq[i];
+        int targeted = 0;
+        {
+            float hk = 1.0e30f;
+            const float tlo = (float)AUG_KNEE_LO * hh;
+            for (int i = 0; i < 3; ++i) {
+                const float g = (i < 2) ? z[i] - c.fc : fmaf(z[2], c.invTg, -c.Qgmin);
+                const float sl = (i < 2) ? k[0][i] : k[0][2] * c.invTg;
+                const float gd = (i < 2) ? c.dgate : c.dgq;
+                const float r = 1.0f / sl;
+                const float t0 = (0.0f - g) * r, t1 = (gd - g) * r;
+                if (t0 > tlo && t0 < hk) hk = t0;
+                if (t1 > tlo && t1 < hk) hk = t1;
+            }
+            const float hcut = hk * (float)AUG_KNEE_OVER;
+            if (!last_chance && hcut < (float)AUG_KNEE_HI * hh) { hh = hcut; targeted = 1; }
+        }
         for (int s = 1; s < 6; ++s) {
             /* stage weights premultiplied by the step, nested FMAs from the first stage outwards -- the kernel's order */
             float hw[5];
@@ -569,8 +606,8 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
                 kink_gw |= kink & (signbit(ug - c.dgq) != 0);
             }
         }
-        if (kink_gw) err *= (float)AUG_KINK_GW;
-        else if (kink) err *= (float)AUG_KINK_SOIL;
+        if (kink_gw) err *= targeted ? (float)AUG_KNEE_GW : (float)AUG_KINK_GW;
+        else if (kink && !targeted) err *= (float)AUG_KINK_SOIL;
         const int bad = !(err < 1.0e30f) || !(fabsf(chk) < 1.0e30f);
         ++attempts;
         if (last_chance) st->capped = 1;
@@ -597,7 +634,7 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
             fac = 0.9f * powf(err, -0.2f);               /* err == 0 -> +inf -> 5 */
             fac = fminf(fmaxf(fac, 0.2f), 5.0f);
         }
-        h = hh * fac;
+        if (!(targeted && accept && hh * fac < h)) h = hh * fac;
         if (attempts % AUG_RESYNC == 0 && t < T) {
             const float lq = logf(z[3]);
             z[9] = expf(c.bQ * lq); z[10] = expf(c.kM * lq);

@@ -293,6 +293,14 @@ __device__ __forceinline__ float sp_rcp_fast(float a) { return __builtin_amdgcn_
 // sign bits of a and b differ <=> the result is negative (one 32-bit xor on the high words)
 __device__ __forceinline__ int sp_sign_xor(double a, double b) { return __double2hiint(a) ^ __double2hiint(b); }
 __device__ __forceinline__ int sp_sign_xor(float a, float b) { return __float_as_int(a) ^ __float_as_int(b); }
+// t if t > lo, else something huge (knee targeting: a candidate time that does not count).  For doubles only the high word is
+// selected -- the low word of t under a huge exponent is still huge -- which saves a v_cndmask per candidate.
+__device__ __forceinline__ double sp_if_above(double t, double lo)
+{
+    const int hi = (t > lo) ? __double2hiint(t) : 0x7e37e43c;       // high word of 1.0e300
+    return __hiloint2double(hi, __double2loint(t));
+}
+__device__ __forceinline__ float sp_if_above(float t, float lo) { return (t > lo) ? t : 1.0e30f; }
 template <typename R> __device__ __forceinline__ R sp_huge();
 template <> __device__ __forceinline__ double sp_huge<double>() { return 1.0e300; }
 template <> __device__ __forceinline__ float sp_huge<float>() { return 1.0e30f; }
@@ -350,6 +358,16 @@ struct SysAug {
     static constexpr bool KINK_AWARE = true;
     static constexpr double KINK_SOIL = 10.0, KINK_GW = 100.0;
     static constexpr double KINK_REACH = 1.25;
+    // Better than paying for a crossing with a rejected attempt: aim at the knee.  After the first stage the time to the
+    // nearest knee along the first slope is known; if it lies inside the step (between KNEE_LO and KNEE_HI of it) the step is
+    // cut to end KNEE_OVER x that far, i.e. just past the knee -- the right-hand side is then smooth over all but the last
+    // few percent of the step, the pair keeps its order, no inflation is applied, and the next step starts on the far side.
+    // The step size carried on is not reduced by such a cut.  Wave-level attempts per day on the bench ensemble 22.2 -> 18.7
+    // (fewer rejections, and lanes that cross a knee no longer hold their wave for 2-3 extra attempts); inflation stays for
+    // crossings the first slope did not announce.
+    // (A step aimed at a knee of the groundwater gate keeps a factor KNEE_GW: where the first slope misjudges the crossing
+    // time the knee sits well inside the step, and that gate does not forgive it -- one member-day of the 100 000 at 1.5e-6.)
+    static constexpr double KNEE_LO = 0.02, KNEE_HI = 0.9, KNEE_OVER = 1.05, KNEE_GW = 10.0;
     static constexpr double AUX_WEIGHT = 3.0;
     // z[9] carries cQ * Qr**b_Q (the factor the flow equation multiplies it with, folded into the state: one multiplication
     // less per right-hand side; its ODE is linear in it, so the scaling changes nothing else)
@@ -432,6 +450,7 @@ struct SysAugF {
     static constexpr bool SOIL_REL = true;
     static constexpr bool KINK_AWARE = true;
     static constexpr double KINK_SOIL = SysAug::KINK_SOIL, KINK_GW = SysAug::KINK_GW, KINK_REACH = SysAug::KINK_REACH;
+    static constexpr double KNEE_LO = SysAug::KNEE_LO, KNEE_HI = SysAug::KNEE_HI, KNEE_OVER = SysAug::KNEE_OVER, KNEE_GW = SysAug::KNEE_GW;
     static constexpr double AUX_WEIGHT = SysAug::AUX_WEIGHT;
     static __device__ __forceinline__ void resync(float (&z)[11], const DayConstF& c)
     {
@@ -549,6 +568,24 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         SYS::f(y, c, k1, kq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = b1 * kq[i]; if (SYS::QUAD_IN_NORM) eq[i] = e1 * kq[i]; }
+        bool targeted = false;
+        if constexpr (SYS::KINK_AWARE) {
+            // time to the nearest knee of a gate along the first slope (SYS::KNEE_*): a knee inside the step ends the step
+            R hk = huge;
+            const R tlo = (R)SYS::KNEE_LO * hh;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const R g = (i < 2) ? y[i] - c.fc : sp_fma(y[2], c.invTg, -c.Qgmin);
+                const R sl = (i < 2) ? k1[i] : k1[2] * c.invTg;
+                const R gd = (i < 2) ? c.dgate : c.dgq;
+                const R r = sp_rcp_fast(sl);
+                const R t0 = ((R)0 - g) * r, t1 = (gd - g) * r;
+                hk = sp_min(hk, sp_min(sp_if_above(t0, tlo), sp_if_above(t1, tlo)));
+            }
+            const R hcut = hk * (R)SYS::KNEE_OVER;
+            targeted = alive && !last_chance && hcut < (R)SYS::KNEE_HI * hh;
+            hh = targeted ? hcut : hh;
+        }
         {
             const R h21 = hh * a21;
 #pragma unroll
@@ -636,7 +673,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
             const R he = sp_fma(he1, k1[10], sp_fma(he3, k3[10], sp_fma(he4, k4[10], sp_fma(he5, k5[10], he6 * k6[10]))));
             const R sc = sp_fma(rtol_aux, sp_absmax(y[10], sp_fma(hh, k1[10], y[10])), atol_aux);
             err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
-            err *= (kink_gw < 0) ? (R)SYS::KINK_GW : ((kink < 0) ? (R)SYS::KINK_SOIL : (R)1);
+            err *= (kink_gw < 0) ? (targeted ? (R)SYS::KNEE_GW : (R)SYS::KINK_GW) : ((kink < 0 && !targeted) ? (R)SYS::KINK_SOIL : (R)1);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -697,7 +734,11 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 cnt.poisoned = true; gave_up_today = true;
             }
         }
-        h = alive ? hh * (R)fac : h;
+        {
+            // (a step that was cut to end at a knee and accepted does not shorten the step size carried on)
+            const R hn = hh * (R)fac;
+            h = alive ? ((targeted && accept && hn < h) ? h : hn) : h;
+        }
         alive = alive && !give_up && (t < T);
         any_alive = __any(alive);
     } while (any_alive && (SYS::RESYNC_EVERY == 0 || (trip % SYS::RESYNC_EVERY) != 0));
@@ -906,6 +947,20 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         R sq;
         quad_rhs(y, k, j_lt2, j_eq2, k1, kq);
         sq = b1 * kq;
+        bool targeted = false;
+        {
+            // time to the nearest knee along the first slope, as in ck_day<SysAug>: this lane's gate, then the quad's minimum
+            const R tlo = SysAug::KNEE_LO * hh;
+            const R g = sp_fma(y[0] - k.eoff, k.gs, k.g0), sl = k1[0] * k.gs;
+            const R r = sp_rcp_fast(sl);
+            const R t0 = (0.0 - g) * r, t1 = (k.gd - g) * r;
+            R hk = sp_min(huge, sp_min(sp_if_above(t0, tlo), sp_if_above(t1, tlo)));
+            hk = __builtin_fmin(hk, quad_perm<SP_QP(1, 0, 3, 2)>(hk));
+            hk = __builtin_fmin(hk, quad_perm<SP_QP(2, 3, 0, 1)>(hk));
+            const R hcut = hk * SysAug::KNEE_OVER;
+            targeted = alive && !last_chance && hcut < SysAug::KNEE_HI * hh;
+            hh = targeted ? hcut : hh;
+        }
         {
             const R h21 = hh * a21;
 #pragma unroll
@@ -985,7 +1040,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
             kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(1, 0, 3, 2), 0xf, 0xf, true);
             kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(2, 3, 0, 1), 0xf, 0xf, true);
             const bool gw = (kink & 2) != 0 || (kink & 5) == 5;
-            err *= gw ? SysAug::KINK_GW : ((kink & 1) ? SysAug::KINK_SOIL : 1.0);
+            err *= gw ? (targeted ? SysAug::KNEE_GW : SysAug::KINK_GW) : (((kink & 1) && !targeted) ? SysAug::KINK_SOIL : 1.0);
         }
         R dq = hh * sq;
         const bool bad = !(err < huge);
@@ -1025,7 +1080,10 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
                 cnt.poisoned = true; gave_up_today = true;
             }
         }
-        h = alive ? hh * (R)fac : h;
+        {
+            const R hn = hh * (R)fac;
+            h = alive ? ((targeted && accept && hn < h) ? h : hn) : h;
+        }
         alive = alive && !give_up && (t < T);
         any_alive = __any(alive);
     } while (any_alive && (trip % SysAug::RESYNC_EVERY) != 0);
