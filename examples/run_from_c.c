@@ -60,7 +60,7 @@ int main(int argc, char** argv)
     simplyp_dims dims = {E, S, D, 1};
     simplyp_opts opts;
     memset(&opts, 0, sizeof(opts));
-    opts.integrator = SIMPLYP_INTEG_CASHKARP_AUG; opts.substeps = 8; opts.rtol = 1e-8; opts.atol = 1e-12; opts.max_steps = 4000;
+    opts.integrator = SIMPLYP_INTEG_CASHKARP_AUG; opts.substeps = 8; opts.rtol = 1e-7; opts.atol = 1e-12; opts.max_steps = 4000;
     opts.dynamic_epc0 = 1; opts.run_mode_cal = 1; opts.out_mask = SIMPLYP_MASK_REACH5; opts.step_len = 1.0; opts.project_vr = 1;
     opts.balance = 2;
     const int32_t up_ptr[2] = {0, 0};

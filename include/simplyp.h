@@ -88,7 +88,11 @@ typedef enum {
     SIMPLYP_INTEG_CASHKARP_AUG = 2, /* same pair and step rule on the augmented form of that system: exp(-mu Vs),
                                     Qr**b_Q, Qr**k_M carried as extra states through their own exact ODEs and
                                     re-evaluated every day, Vr taken from its invariant -- no transcendental in
-                                    the right-hand side.  Default.                        */
+                                    the right-hand side.  Default.  Its step controller knows
+                                    the knees of the reference's smooth-step gates (f_x, model.py:23-37: C1 only):
+                                    steps are aimed at them, and the error estimate of a step that crosses one
+                                    unannounced is not trusted -- parity-grade (<= 1e-6 against odeint at
+                                    rtol=atol=1e-12) at rtol 1e-7.                                               */
     SIMPLYP_INTEG_CASHKARP_AUG_F32 = 3 /* scheme 2 with the stage arithmetic in fp32 (BASELINE config C5): 11 float states per
                                     member inside the day's integration; the four daily integrals, the carried state,
                                     labile soil P / soil-water TDP and the day constants stay fp64.  Meant for
@@ -105,7 +109,8 @@ typedef struct {
 typedef struct {
     int32_t  integrator;     /* simplyp_integrator                                         */
     int32_t  substeps;       /* RK4: steps per day.  Cash-Karp: first trial step = step_len/substeps */
-    double   rtol;           /* Cash-Karp: err_i <= atol + rtol*max(|y_i|,|y_i + h k1_i|)  */
+    double   rtol;           /* Cash-Karp: err_i <= atol + rtol*max(|y_i|,|y_i + h k1_i|)  (schemes 2, 3: the soil boxes
+                                measured from field capacity)          */
     double   atol;
     int32_t  max_steps;      /* Cash-Karp: attempted steps per day before SIMPLYP_STATUS_STEPCAP */
     int32_t  dynamic_epc0;   /* dynamic_options['Dynamic_EPC0'] == 'y'  (model.py:600,684) */

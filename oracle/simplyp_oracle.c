@@ -447,7 +447,7 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
  */
 typedef struct {
     float c0, aE, mu, fc, inv_d, invTsA, invTsS, invTg, Qgmin, inv_dg, beta, fA, fS, qin, omb, cQ, bQ, kM,
-          Esum, MsusUS, tA, tS, tg, tconst, cPP, PPrUS, invKv, dgate, dgq;
+          Esum, MsusUS, tA, tS, tg, tconst, cPP, PPrUS, invKv;
 } dayconst_f;
 
 static float gate_f(float u, float inv_d)            /* f_x as one clamped cubic, like the kernel's gate() */
@@ -489,8 +489,6 @@ static void dayconst_from_params(const ode_params* p, dayconst_f* c)
                                 + p->f_S * p->Esus_S * ((1 - p->f_NC_S) * p0 + p->f_NC_S * pN)));
     c->PPrUS = (float)p->PPr_US_i;
     c->invKv = (float)(1.0 / Kv);
-    c->dgate = (float)(0.01 * p->fc);
-    c->dgq = (float)(0.01 * p->Qg_min);
 }
 
 /* SysAugF::f, operation for operation.  z[11] = VsA VsS Vg Qr Msus TDPr PPr EA ES pb pk; q[4] = integrands of the
@@ -554,22 +552,6 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
         if (last_chance) hh = rem;
         ode_aug_f32(z, &c, k[0], kq);
         for (int i = 0; i < 4; ++i) sq[i] = B[0] * kq[i];
-        int targeted = 0;
-        {
-            float hk = 1.0e30f;
-            const float tlo = (float)AUG_KNEE_LO * hh;
-            for (int i = 0; i < 3; ++i) {
-                const float g = (i < 2) ? z[i] - c.fc : fmaf(z[2], c.invTg, -c.Qgmin);
-                const float sl = (i < 2) ? k[0][i] : k[0][2] * c.invTg;
-                const float gd = (i < 2) ? c.dgate : c.dgq;
-                const float r = 1.0f / sl;
-                const float t0 = (0.0f - g) * r, t1 = (gd - g) * r;
-                if (t0 > tlo && t0 < hk) hk = t0;
-                if (t1 > tlo && t1 < hk) hk = t1;
-            }
-            const float hcut = hk * (float)AUG_KNEE_OVER;
-            if (!last_chance && hcut < (float)AUG_KNEE_HI * hh) { hh = hcut; targeted = 1; }
-        }
         for (int s = 1; s < 6; ++s) {
             /* stage weights premultiplied by the step, nested FMAs from the first stage outwards -- the kernel's order */
             float hw[5];
@@ -585,29 +567,13 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
         st->rhs += 6;
         float err = 0.0f, chk = 0.0f;
         const float he[6] = {hh * Ee[0], 0.0f, hh * Ee[2], hh * Ee[3], hh * Ee[4], hh * Ee[5]};
-        int kink = 0, kink_gw = 0;
-        for (int i = 0; i < NS; ++i) {
-            if (i >= AUG_NERR && i != 10) continue;       /* the 7 physical states + Qr**k_M, as in cashkarp_aug_day */
+        for (int i = 0; i < AUG_NERR; ++i) {          /* the plain controller: SysAugF has no knee logic (see the kernel) */
             const float e = fmaf(he[0], k[0][i], fmaf(he[2], k[2][i], fmaf(he[3], k[3][i], fmaf(he[4], k[4][i], he[5] * k[5][i]))));
-            if (i >= 3 && i < AUG_NERR) chk += e;
-            const float ref = (i < 2) ? z[i] - c.fc : z[i];
-            const float pred = fmaf(hh, k[0][i], ref);
-            float w = fmaxf(fabsf(ref), fabsf(pred));
-            if (i < 2) w = fmaxf(w, c.dgate);
-            const float sc = (i == 10) ? fmaf((float)AUG_AUX_WEIGHT * rtol, w, (float)AUG_AUX_WEIGHT * atol) : fmaf(rtol, w, atol);
+            if (i >= 3) chk += e;
+            const float sc = fmaf(rtol, fmaxf(fabsf(z[i]), fabsf(fmaf(hh, k[0][i], z[i]))), atol);
             const float r = fabsf(e) * (1.0f / sc);
             if (r > err) err = r;
-            const float far = fmaf(hh * (float)AUG_KINK_REACH, k[0][i], ref);
-            if (i < 2)
-                kink |= (signbit(ref) != signbit(far)) | (signbit(ref - c.dgate) != signbit(far - c.dgate));
-            if (i == 2) {
-                const float ug = fmaf(ref, c.invTg, -c.Qgmin), up = fmaf(far, c.invTg, -c.Qgmin);
-                kink_gw = (signbit(ug) != signbit(up)) | (signbit(ug - c.dgq) != signbit(up - c.dgq));
-                kink_gw |= kink & (signbit(ug - c.dgq) != 0);
-            }
         }
-        if (kink_gw) err *= targeted ? (float)AUG_KNEE_GW : (float)AUG_KINK_GW;
-        else if (kink && !targeted) err *= (float)AUG_KINK_SOIL;
         const int bad = !(err < 1.0e30f) || !(fabsf(chk) < 1.0e30f);
         ++attempts;
         if (last_chance) st->capped = 1;
@@ -634,7 +600,7 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
             fac = 0.9f * powf(err, -0.2f);               /* err == 0 -> +inf -> 5 */
             fac = fminf(fmaxf(fac, 0.2f), 5.0f);
         }
-        if (!(targeted && accept && hh * fac < h)) h = hh * fac;
+        h = hh * fac;
         if (attempts % AUG_RESYNC == 0 && t < T) {
             const float lq = logf(z[3]);
             z[9] = expf(c.bQ * lq); z[10] = expf(c.kM * lq);

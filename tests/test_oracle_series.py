@@ -181,9 +181,9 @@ def test_oracle_default_solver_across_parameter_distribution(oracle_lib):
 def test_fp32_stage_mirror_is_a_valid_integration_at_its_tolerance(oracle_lib, name):
     """oracle integrator 3 (the same-arithmetic mirror of the kernel's fp32-stage mode, BASELINE config C5) against the
     reference's converged tables: 5e-4 on the 9 reach columns at rtol 1e-5 -- the bar the GPU test holds the kernel to --
-    and about as many right-hand-side evaluations (5 %) as the fp64 scheme at that tolerance.  (Both run the same step
-    controller; the fp64 scheme is 5 x more accurate at this tolerance since the controller holds the soil boxes to
-    rtol * |Vs - fc| -- at rtol 1e-5 that is one float ulp of a 300 mm store, which fp32 stages cannot deliver.)"""
+    and about as many right-hand-side evaluations (10 %) as the fp64 scheme at that tolerance.  (The fp32 mode keeps the
+    plain step controller: the knee logic of the fp64 scheme holds the soil boxes to rtol * |Vs - fc| -- at rtol 1e-5 one
+    float ulp of a 300 mm store, which fp32 stages cannot deliver -- and costs it a few percent more evaluations here.)"""
     gold = helpers.golden_tables(name, 'tight')
     res = {}
     for integ in ('cashkarp_aug_f32', 'cashkarp_aug'):
@@ -193,4 +193,4 @@ def test_fp32_stage_mirror_is_a_valid_integration_at_its_tolerance(oracle_lib, n
         res[integ] = (max(helpers.max_rel_err(out[marshal.OUT_COLUMNS.index(c), :, j, 0], gold['R'][sc][c].values, floor=1e-300)
                           for j, sc in enumerate(m['scs']) for c in REACH_COLS), stats['rhs_evals'])
     assert res['cashkarp_aug_f32'][0] < 5e-4 and res['cashkarp_aug'][0] < 5e-4, res
-    assert abs(res['cashkarp_aug_f32'][1] - res['cashkarp_aug'][1]) < 0.05 * res['cashkarp_aug'][1], res
+    assert abs(res['cashkarp_aug_f32'][1] - res['cashkarp_aug'][1]) < 0.10 * res['cashkarp_aug'][1], res
