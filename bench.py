@@ -346,6 +346,8 @@ def main():
                          "d2h_tail_ms": float(np.mean([s['d2h_tail_ms'] for s in step_stats])),
                          "streamed_chunks": int(step_stats[-1]['streamed_chunks']),
                          "d2h_gbs_over_run": None if host_out is None else out_bytes / (float(np.mean([s['wall_ms'] for s in step_stats])) * 1e-3) / 1e9,
+                         "stream_gbs_device_clock": [round(float(s_.get('stream_gbs', 0.0)), 2) for s_ in step_stats],
+                         "chunks_per_copy": [int(s_.get('copy_group', 0)) for s_ in step_stats],
                          "pcie_spec_gbs": PCIE_SPEC_GBS, "host_numa_node": numa_node, "note": stream_note},
             "occupancy": {"members_per_wave": lanes, "lanes_per_member": int(stats.get('lanes_per_member', 1) or 1),
                           "waves_per_gpu": waves, "simd_slots": 1024, "rounds": waves / 1024.0,

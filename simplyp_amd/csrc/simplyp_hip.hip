@@ -52,6 +52,12 @@ struct simplyp_ctx {
     hipStream_t copy_streams[N_COPY_STREAMS] = {};      // the chunk copies take these in turn
     hipEvent_t ev_copy_done = nullptr, ev_copy_join[N_COPY_STREAMS] = {};
     int n_copy_streams = 2;
+    // Time chunks per copy.  1 = every finished chunk travels at once (one copy per column, 51 MB for C3).  Some hosts add
+    // ~0.25 ms to every such copy (streamed rate 44.9 instead of 55.9 GB/s, while a single 8 GB copy makes 57.1 on the same
+    // box: profiles/r02_experiments.md); when a chunked, copy-bound run comes out below COPY_SLOW_GBS the context switches to 4
+    // chunks per copy for its later runs (fewer, larger copies; the first one starts ~15 ms later).  SIMPLYP_COPY_GROUP forces it.
+    int copy_group = 1;
+    static constexpr double COPY_SLOW_GBS = 50.0;
     double* stream_host = nullptr;      // armed for the next run (one-shot)
     int64_t stream_host_bytes = 0;
     uint32_t* host_ready = nullptr;     // [host_ready_cap] hipHostMalloc
@@ -60,7 +66,8 @@ struct simplyp_ctx {
     struct CopyPlan {
         const double* dev = nullptr;
         double* host = nullptr;
-        int ncols = 0, n_chunks = 0, chunk_days = 0;
+        int ncols = 0, n_chunks = 0, chunk_days = 0, group = 1;
+        bool group_forced = false;      // this run's group came from SIMPLYP_COPY_GROUP: the context does not learn from it
         size_t D = 0, row_doubles = 0;  // rows per column, doubles per row (n_out_reaches * E)
     } copy_plan;
     std::thread copier;
@@ -354,16 +361,20 @@ void copier_main(simplyp_ctx* ctx)
     bool run_over = false;
     unsigned n_issued = 0;
     const bool dbg = getenv("SIMPLYP_DEBUG") != nullptr;
-    for (int c = 0; c < p.n_chunks; ++c) {
-        while (!run_over && __atomic_load_n(&ctx->host_ready[c], __ATOMIC_ACQUIRE) == 0u) {
-            if (ctx->run_over.load(std::memory_order_acquire)) { run_over = true; break; }
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
+    const int group = std::max(1, p.group);
+    for (int c0 = 0; c0 < p.n_chunks; c0 += group) {
+        const int c1 = std::min(p.n_chunks, c0 + group);       // chunks [c0, c1) travel as one copy per column
+        for (int c = c0; c < c1; ++c) {
+            while (!run_over && __atomic_load_n(&ctx->host_ready[c], __ATOMIC_ACQUIRE) == 0u) {
+                if (ctx->run_over.load(std::memory_order_acquire)) { run_over = true; break; }
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            if (!run_over) ++ctx->streamed_chunks;
+            if (dbg && (c < 3 || c + 2 > p.n_chunks))
+                fprintf(stderr, "[simplyp] copier: chunk %d ready=%u over=%d at %.1f ms\n", c, ctx->host_ready[c], (int)run_over,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count());
         }
-        if (!run_over) ++ctx->streamed_chunks;
-        if (dbg && (c < 3 || c + 2 > p.n_chunks))
-            fprintf(stderr, "[simplyp] copier: chunk %d ready=%u over=%d at %.1f ms\n", c, ctx->host_ready[c], (int)run_over,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count());
-        const size_t d0 = (size_t)c * p.chunk_days, nd = std::min<size_t>(p.chunk_days, p.D - d0);
+        const size_t d0 = (size_t)c0 * p.chunk_days, nd = std::min<size_t>((size_t)(c1 - c0) * p.chunk_days, p.D - d0);
         // (one plain copy per column: a pitched hipMemcpy2DAsync per chunk does not overlap the persistent kernel at all on this
         // stack -- 1509 ms per pass instead of 803, profiles/r02_experiments.md)
         for (int j = 0; j < p.ncols; ++j) {
@@ -585,6 +596,7 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     const int64_t host_out_bytes = ctx->stream_host_bytes;
     ctx->stream_host = nullptr; ctx->stream_host_bytes = 0;
     ctx->copy_pending = false; ctx->copy_error = 0; ctx->streamed_chunks = 0;
+    ctx->copy_plan.n_chunks = 0; ctx->copy_plan.group = 1; ctx->copy_plan.group_forced = false;
     if (host_out && host_out_bytes < simplyp_out_bytes(dims, opts, out_reaches ? n_out_reaches : dims->S))
         return fail(ctx, SIMPLYP_ERR_ARG, "simplyp_stream_out: host buffer of %lld bytes is smaller than the output table (%lld)",
                     (long long)host_out_bytes, (long long)simplyp_out_bytes(dims, opts, out_reaches ? n_out_reaches : dims->S));
@@ -915,6 +927,12 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
                 q.host_ready = ctx->host_ready;
                 ctx->copy_plan.n_chunks = n_chunks;
                 ctx->copy_plan.chunk_days = chunk_days;
+                ctx->copy_plan.group = ctx->copy_group;
+                ctx->copy_plan.group_forced = false;
+                if (const char* g_env = getenv("SIMPLYP_COPY_GROUP")) {
+                    ctx->copy_plan.group = std::max(1, std::min(64, atoi(g_env)));
+                    ctx->copy_plan.group_forced = true;
+                }
             }
             q.max_polls = 20000000u;      // x (s_sleep 64 ~ 2 us): a wait longer than ~40 s means something is broken
             if (const char* mp_env = getenv("SIMPLYP_QUEUE_MAX_POLLS")) q.max_polls = (unsigned)strtoul(mp_env, nullptr, 10);
@@ -1019,6 +1037,8 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] sync: stream idle\n");
     float ms_tail = 0.f;
+    double stream_gbs = 0.0;
+    int used_group = 0;
     const bool copied = ctx->copy_pending;
     if (ctx->copy_pending) {
         ctx->copy_pending = false;
@@ -1028,6 +1048,18 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
             return fail(ctx, SIMPLYP_ERR_DEVICE, "streamed output: a device-to-host copy failed: %s", hipGetErrorString((hipError_t)ctx->copy_error));
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev_copy_done));
         HIP_TRY(ctx, hipEventElapsedTime(&ms_tail, ctx->ev_stop, ctx->ev_copy_done));
+        if (ctx->queued && ctx->copy_plan.n_chunks > 0) {
+            // chunked run: the rate the table travelled at, and whether this host wants fewer, larger copies from now on
+            float ms_run = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms_run, ctx->ev_main, ctx->ev_copy_done));
+            const simplyp_ctx::CopyPlan& cp = ctx->copy_plan;
+            const double bytes = (double)cp.ncols * (double)cp.D * (double)cp.row_doubles * sizeof(double);
+            stream_gbs = ms_run > 0.f ? bytes / (ms_run * 1e-3) / 1e9 : 0.0;
+            used_group = cp.group;
+            const bool copy_bound = ms_tail > 0.1f * ms_run && cp.n_chunks >= 16;
+            if (!cp.group_forced && ctx->copy_group == 1 && copy_bound && stream_gbs < simplyp_ctx::COPY_SLOW_GBS)
+                ctx->copy_group = 4;
+        }
     }
     if (ctx->queued) {
         unsigned err = 0;
@@ -1054,6 +1086,8 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->lanes_per_member = ctx->team;
         stats->streamed_chunks = copied ? ctx->streamed_chunks : 0;
         stats->d2h_tail_ms = copied ? ms_tail : 0.0;
+        stats->stream_gbs = stream_gbs;
+        stats->copy_group = used_group;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();
     }
     return SIMPLYP_OK;

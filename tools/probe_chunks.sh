@@ -8,10 +8,11 @@ run() {
   python -c "
 import json
 d=json.load(open('gpurun_out/r02s/bench_$1.json'))
-print('chunk_days', $1, 'ms/step %.1f kernel %.1f tail %.1f chunks %d d2h %.1f GB/s' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['transfer']['d2h_tail_ms'], d['transfer']['streamed_chunks'], d['transfer']['d2h_gbs_over_run']))
+print('chunk_days', $1, 'ms/step %.1f kernel %.1f tail %.1f chunks %d d2h %.1f GB/s' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['transfer']['d2h_tail_ms'], d['transfer']['streamed_chunks'], d['transfer']['d2h_gbs_over_run']), 'chunks per copy', d['transfer']['chunks_per_copy'], 'device-clock GB/s', d['transfer']['stream_gbs_device_clock'])
 open('gpurun_out/r02s/last_ms','w').write(str(int(d['ms_per_step'])))"
 }
 run 64
 if [ "$1" = quick ] && [ "$(cat gpurun_out/r02s/last_ms)" -lt 880 ]; then echo "fast box: nothing to learn here"; exit 0; fi
 for cd in 128 256 512 1024; do run $cd; done
+for g in 1 2 4 8; do echo "SIMPLYP_COPY_GROUP=$g"; SIMPLYP_COPY_GROUP=$g run 64; done
 python tools/probe_d2h_numa.py 8
