@@ -301,6 +301,15 @@ __device__ __forceinline__ double sp_if_above(double t, double lo)
     return __hiloint2double(hi, __double2loint(t));
 }
 __device__ __forceinline__ float sp_if_above(float t, float lo) { return (t > lo) ? t : 1.0e30f; }
+// min of two finite or huge values as ONE instruction (the builtin first canonicalises operands it cannot prove quiet -- the
+// bit-assembled results of sp_if_above -- with a v_max_f64 x, x each)
+__device__ __forceinline__ double sp_min_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float sp_min_raw(float a, float b) { return __builtin_fminf(a, b); }
 template <typename R> __device__ __forceinline__ R sp_huge();
 template <> __device__ __forceinline__ double sp_huge<double>() { return 1.0e300; }
 template <> __device__ __forceinline__ float sp_huge<float>() { return 1.0e30f; }
@@ -578,7 +587,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 const R gd = (i < 2) ? c.dgate : c.dgq;
                 const R r = sp_rcp_fast(sl);
                 const R t0 = ((R)0 - g) * r, t1 = (gd - g) * r;
-                hk = sp_min(hk, sp_min(sp_if_above(t0, tlo), sp_if_above(t1, tlo)));
+                hk = sp_min_raw(hk, sp_min_raw(sp_if_above(t0, tlo), sp_if_above(t1, tlo)));
             }
             const R hcut = hk * (R)SYS::KNEE_OVER;
             targeted = alive && !last_chance && hcut < (R)SYS::KNEE_HI * hh;
@@ -952,9 +961,9 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
             const R g = sp_fma(y[0] - k.eoff, k.gs, k.g0), sl = k1[0] * k.gs;
             const R r = sp_rcp_fast(sl);
             const R t0 = (0.0 - g) * r, t1 = (k.gd - g) * r;
-            R hk = sp_min(huge, sp_min(sp_if_above(t0, tlo), sp_if_above(t1, tlo)));
-            hk = __builtin_fmin(hk, quad_perm<SP_QP(1, 0, 3, 2)>(hk));
-            hk = __builtin_fmin(hk, quad_perm<SP_QP(2, 3, 0, 1)>(hk));
+            R hk = sp_min_raw(huge, sp_min_raw(sp_if_above(t0, tlo), sp_if_above(t1, tlo)));
+            hk = sp_min_raw(hk, quad_perm<SP_QP(1, 0, 3, 2)>(hk));
+            hk = sp_min_raw(hk, quad_perm<SP_QP(2, 3, 0, 1)>(hk));
             const R hcut = hk * SysAug::KNEE_OVER;
             targeted = alive && !last_chance && hcut < SysAug::KNEE_HI * hh;
             hh = targeted ? hcut : hh;
