@@ -184,9 +184,8 @@ typedef struct {
     double   wall_ms;        /* host wall clock from the entry of simplyp_run / simplyp_run_async to the end of simplyp_sync */
     double   stream_gbs;     /* simplyp_stream_out, chunked runs: table bytes / device time from the start of the main launch to
                                 the last output byte in the host buffer, GB/s (0 otherwise)                          */
-    int32_t  copy_group;     /* simplyp_stream_out, chunked runs: time chunks per device-to-host copy this run used.  1 at first;
-                                a context whose copy-bound streamed run came out below 50 GB/s (some hosts add ~0.25 ms to
-                                every copy) uses 4 from its next run on: fewer, larger copies.  SIMPLYP_COPY_GROUP forces it. */
+    int32_t  copy_group;     /* simplyp_stream_out, chunked runs: time chunks per device-to-host copy this run used: 1, or
+                                what the environment variable SIMPLYP_COPY_GROUP asked for (a diagnostic)               */
     int32_t  reserved0;
 } simplyp_stats;
 

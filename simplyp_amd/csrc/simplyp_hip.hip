@@ -52,12 +52,10 @@ struct simplyp_ctx {
     hipStream_t copy_streams[N_COPY_STREAMS] = {};      // the chunk copies take these in turn
     hipEvent_t ev_copy_done = nullptr, ev_copy_join[N_COPY_STREAMS] = {};
     int n_copy_streams = 2;
-    // Time chunks per copy.  1 = every finished chunk travels at once (one copy per column, 51 MB for C3).  Some hosts add
-    // ~0.25 ms to every such copy (streamed rate 44.9 instead of 55.9 GB/s, while a single 8 GB copy makes 57.1 on the same
-    // box: profiles/r02_experiments.md); when a chunked, copy-bound run comes out below COPY_SLOW_GBS the context switches to 4
-    // chunks per copy for its later runs (fewer, larger copies; the first one starts ~15 ms later).  SIMPLYP_COPY_GROUP forces it.
+    // Time chunks per copy: 1 = every finished chunk travels at once (one copy per column, 51 MB for C3); SIMPLYP_COPY_GROUP = n
+    // sends n chunks per copy (a diagnostic: on this pool a streamed pass sometimes runs at 45-50 instead of 56 GB/s for a
+    // minute or so, on the same box with the same settings -- larger copies do not cure it: profiles/r02_experiments.md)
     int copy_group = 1;
-    static constexpr double COPY_SLOW_GBS = 50.0;
     double* stream_host = nullptr;      // armed for the next run (one-shot)
     int64_t stream_host_bytes = 0;
     uint32_t* host_ready = nullptr;     // [host_ready_cap] hipHostMalloc
@@ -1049,16 +1047,13 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev_copy_done));
         HIP_TRY(ctx, hipEventElapsedTime(&ms_tail, ctx->ev_stop, ctx->ev_copy_done));
         if (ctx->queued && ctx->copy_plan.n_chunks > 0) {
-            // chunked run: the rate the table travelled at, and whether this host wants fewer, larger copies from now on
+            // chunked run: the rate the table travelled at
             float ms_run = 0.f;
             HIP_TRY(ctx, hipEventElapsedTime(&ms_run, ctx->ev_main, ctx->ev_copy_done));
             const simplyp_ctx::CopyPlan& cp = ctx->copy_plan;
             const double bytes = (double)cp.ncols * (double)cp.D * (double)cp.row_doubles * sizeof(double);
             stream_gbs = ms_run > 0.f ? bytes / (ms_run * 1e-3) / 1e9 : 0.0;
             used_group = cp.group;
-            const bool copy_bound = ms_tail > 0.1f * ms_run && cp.n_chunks >= 16;
-            if (!cp.group_forced && ctx->copy_group == 1 && copy_bound && stream_gbs < simplyp_ctx::COPY_SLOW_GBS)
-                ctx->copy_group = 4;
         }
     }
     if (ctx->queued) {

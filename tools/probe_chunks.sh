@@ -1,7 +1,7 @@
 #!/bin/bash
-# Streamed pass of the C3 bench against the copy granularity (opts.time_chunk_days), on whatever box this lands on.  Some boxes
-# stream 860 copies of 51 MB at 44.9 GB/s where others reach 55.9 (a plain 8 GB copy makes 57.1 on both): `quick` stops after
-# the first measurement on a fast box.     Usage: bash tools/probe_chunks.sh [quick]
+# Streamed pass of the C3 bench against the copy granularity (opts.time_chunk_days, SIMPLYP_COPY_GROUP), on whatever box this lands on.
+# Now and then a pass streams at 45-50 instead of 56 GB/s (profiles/r02_experiments.md): `quick` stops after
+# the first measurement when that one is fast.     Usage: bash tools/probe_chunks.sh [quick]
 mkdir -p gpurun_out/r02s
 run() {
   timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --chunk-days $1 > gpurun_out/r02s/bench_$1.json 2> gpurun_out/r02s/bench_$1.err
