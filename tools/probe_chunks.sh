@@ -13,6 +13,8 @@ open('gpurun_out/r02s/last_ms','w').write(str(int(d['ms_per_step'])))"
 }
 run 64
 if [ "$1" = quick ] && [ "$(cat gpurun_out/r02s/last_ms)" -lt 880 ]; then echo "fast box: nothing to learn here"; exit 0; fi
+echo "slow spell: plain copies right now"; python tools/probe_d2h_numa.py 8
+run 64
 for cd in 128 256 512 1024; do run $cd; done
 for g in 1 2 4 8; do echo "SIMPLYP_COPY_GROUP=$g"; SIMPLYP_COPY_GROUP=$g run 64; done
 python tools/probe_d2h_numa.py 8
