@@ -656,3 +656,27 @@ def test_random_reach_networks_match_the_oracle(engine0, oracle_lib, seed):
             queue, qs, qst = gpu_run(engine0, m)
             assert qst['queued'] == 1
             assert np.array_equal(queue, chain, equal_nan=True) and np.array_equal(qs, cs)
+
+
+def test_knee_aware_controller_on_the_members_that_needed_it(engine0, oracle_lib):
+    """Six members of the bench's 100 000-member ensemble whose worst day, under a plain relative-tolerance controller, was a step
+    across a knee of one of the reference's gates (tests/test_oracle_series.py::KNEE_MEMBERS): the kernel's default solver against
+    the same kernel at rtol 1e-11 below 5e-7 on every REACH-5 value of 30 years, one lane and four lanes per member alike, and
+    within 10 x rtol of the CPU oracle's run."""
+    from test_oracle_series import KNEE_MEMBERS
+    pr = synthetic.c3_problem(100000)
+    m = dict(pr, member_params=np.ascontiguousarray(pr['member_params'][:, KNEE_MEMBERS]),
+             reach_params=np.ascontiguousarray(pr['reach_params'][:, :, KNEE_MEMBERS]))
+    rtol, atol = m['opts'].rtol, m['opts'].atol
+    m['opts'].rtol, m['opts'].atol = 1e-11, 1e-13
+    truth, st, _ = gpu_run(engine0, m)
+    assert st.max() == 0
+    m['opts'].rtol, m['opts'].atol = rtol, atol
+    ref, rst, _ = cpu_run(oracle_lib, m, n_threads=6)
+    for lanes in (1, 4):
+        m['opts'].lanes_per_member = lanes
+        got, st, stats = gpu_run(engine0, m)
+        assert st.max() == 0 and stats['lanes_per_member'] == lanes
+        worst = (np.abs(got - truth) / np.maximum(np.abs(truth), 1e-300)).max(axis=(0, 1, 2))
+        assert worst.max() < 5e-7, (lanes, dict(zip(KNEE_MEMBERS, worst)))
+        assert helpers.max_rel_err(got, ref, floor=FLOOR) < helpers.TOL_WORKING

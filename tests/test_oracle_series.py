@@ -194,3 +194,38 @@ def test_fp32_stage_mirror_is_a_valid_integration_at_its_tolerance(oracle_lib, n
                           for j, sc in enumerate(m['scs']) for c in REACH_COLS), stats['rhs_evals'])
     assert res['cashkarp_aug_f32'][0] < 5e-4 and res['cashkarp_aug'][0] < 5e-4, res
     assert abs(res['cashkarp_aug_f32'][1] - res['cashkarp_aug'][1]) < 0.10 * res['cashkarp_aug'][1], res
+
+
+# Members of the bench's 100 000-member ensemble whose worst day, under a plain relative-tolerance controller, was a step
+# across a knee of one of the reference's smooth-step gates (f_x, model.py:23-37: C1 only).  Found with tools/probe_tolerance.py
+# and tools/probe_member.py; profiles/r02_experiments.md.  53752, 60773: the groundwater gate on a recession (5.3e-7 at rtol
+# 1e-8, 1.9e-6 at 2e-8); 37627: a soil box starts to drain while Vg sits at its floor; 41834: a nearly dry reach is wetted
+# (Qr**k_M grows 200-fold within the day); 71711, 27305: groundwater gate / sediment flux at low flow.
+KNEE_MEMBERS = [53752, 60773, 37627, 41834, 71711, 27305]
+
+
+def test_knee_aware_controller_on_the_members_that_needed_it(oracle_lib):
+    """The default solver (knee-aware step controller, rtol 1e-7) on those members, 30 years, REACH-5 columns, against the same
+    scheme at rtol 1e-11 (which test_oracle_converged_matches_reference_tight pins to the reference's tight tables): every one
+    of them below 5e-7 -- and at a cost in right-hand sides that stays where the bench line reports it."""
+    from simplyp_amd import synthetic
+    pr = synthetic.c3_problem(100000)
+    mp = np.ascontiguousarray(pr['member_params'][:, KNEE_MEMBERS])
+    rp = np.ascontiguousarray(pr['reach_params'][:, :, KNEE_MEMBERS])
+    D = pr['forcing'].shape[2]
+
+    def run(rtol, atol):
+        pr['opts'].rtol, pr['opts'].atol = rtol, atol
+        out, status, stats = oracle_lib.run(pr['forcing'], pr['doy'], mp, rp, pr['up_ptr'], pr['up_idx'], pr['opts'], n_threads=6)
+        assert status.max() == 0
+        return out, stats
+
+    default_rtol, default_atol = pr['opts'].rtol, pr['opts'].atol
+    assert default_rtol == 1e-7
+    truth, _ = run(1e-11, 1e-13)
+    out, stats = run(default_rtol, default_atol)
+    rel = np.abs(out - truth) / np.maximum(np.abs(truth), 1e-300)
+    worst = rel.max(axis=(0, 1, 2))
+    assert worst.max() < 5e-7, dict(zip(KNEE_MEMBERS, worst))
+    # (these are low-flow members: fewer steps than the ensemble's 87 right-hand sides per catchment-day)
+    assert 55 < stats['rhs_evals'] / (len(KNEE_MEMBERS) * D) < 95
