@@ -267,6 +267,7 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
 #define AUG_KNEE_LO 0.02         /* SysAug::KNEE_LO, KNEE_HI, KNEE_OVER: a knee between 2 % and 90 % of the step, along the */
 #define AUG_KNEE_HI 0.9          /* first slope, ends the step 5 % past the knee (no inflation for such a step)            */
 #define AUG_KNEE_OVER 1.05
+#define AUG_DAY_START 0.2        /* SysAug::DAY_START: share of the carried step size a new day starts with */
 #define AUG_KNEE_GW 10.0          /* SysAug::KNEE_GW: a step aimed at a knee of the groundwater gate keeps this factor */
 #define AUG_KINK_GW 100.0        /* SysAug::KINK_GW: across a knee of the groundwater gate (zone 1 % of Qg_min wide) */
 static void ode_aug(const double* z, const ode_params* p, double invKv, double* dz)
@@ -314,7 +315,9 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
                              int max_steps, double* h_carry, integ_stats* st)
 {
     double k[6][NZ], zt[NZ], zn[NZ], z[NZ];
-    double t = 0.0, h = *h_carry;
+    /* (the step size carried over the day boundary belongs to the smooth end of a day; the forcing jumps at midnight and the first
+     * attempt of the new day with it was rejected on 85 % of the member-days: SysAug::DAY_START of it is the better guess) */
+    double t = 0.0, h = *h_carry * AUG_DAY_START;
     int attempts = 0;
     const double Kv = p->L_reach / (p->a_Q * 8.64 * 10000), invKv = 1.0 / Kv;
     if (!(h > 0.0) || h > T) h = T;
@@ -331,19 +334,30 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
         ode_aug(z, p, invKv, k[0]);
         /* Aim at the knee (SysAug::KNEE_*): time to the nearest knee of a gate along the first slope; a knee inside the step
          * ends the step just past it, so that the right-hand side is smooth over all but its last few percent. */
-        int targeted = 0;
+        int targeted = 0, kink = 0, kink_gw = 0;
         {
-            double hk = 1.0e300;
+            double hs = 1.0e300, hg = 1.0e300, ugd = 0.0;      /* soil boxes, groundwater; Qg gate: upper knee minus Vg / T_g - Qg_min */
             const double tlo = AUG_KNEE_LO * hh, invTg = 1.0 / p->T_g;
             for (int i = 0; i < 3; ++i) {
                 const double g = (i < 2) ? z[i] - p->fc : z[2] * invTg - p->Qg_min;
                 const double sl = (i < 2) ? k[0][i] : k[0][2] * invTg;
                 const double gd = (i < 2) ? 0.01 * p->fc : 0.01 * p->Qg_min;
-                const double t0 = (0.0 - g) / sl, t1 = (gd - g) / sl;
-                if (t0 > tlo && t0 < hk) hk = t0;
-                if (t1 > tlo && t1 < hk) hk = t1;
+                const double gdg = gd - g;
+                const double t0 = (0.0 - g) / sl, t1 = gdg / sl;
+                double tn = 1.0e300;
+                if (t0 > tlo && t0 < tn) tn = t0;
+                if (t1 > tlo && t1 < tn) tn = t1;
+                if (i < 2) { if (tn < hs) hs = tn; } else { hg = tn; ugd = gdg; }
             }
+            const double hk = fmin(hs, hg);
             if (!last_chance && hk * AUG_KNEE_OVER < AUG_KNEE_HI * hh) { hh = hk * AUG_KNEE_OVER; targeted = 1; }
+            /* A knee within AUG_KINK_REACH x the step along the first slope that the step was not aimed at: its estimate is not
+             * trusted (SysAug::KINK_*).  A soil box that starts to drain within the step can lift Vg through its gate within the
+             * same step, which the slope at the step's start (-Qg) cannot see: a soil knee within reach while Vg / T_g is below
+             * the upper knee of its gate counts as a groundwater knee too. */
+            const double look = AUG_KINK_REACH * hh;
+            kink = hs < look;
+            kink_gw = (hg < look) | (kink & (ugd > 0.0));
         }
         for (int s = 1; s < 6; ++s) {
             for (int i = 0; i < NZ; ++i) {
@@ -354,7 +368,7 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
             ode_aug(zt, p, invKv, k[s]);
         }
         st->rhs += 6;
-        double err = 0.0; int bad = 0, kink = 0, kink_gw = 0;
+        double err = 0.0; int bad = 0;
         for (int i = 0; i < NZ; ++i) {
             double inc = 0.0, ee = 0.0;
             for (int s = 0; s < 6; ++s) { inc += CK_B[s] * k[s][i]; ee += CK_E[s] * k[s][i]; }
@@ -376,21 +390,6 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
             if (i == 10) sc = AUG_AUX_WEIGHT * atol + (AUG_AUX_WEIGHT * rtol) * w;
             double r = fabs(hh * ee) / sc;
             if (r > err) err = r;
-            /* Steps across a knee of a gate (SysAug::KINK_AWARE): f_x (model.py:23-37) is C1 only, so where a soil box crosses
-             * fc or 1.01 fc, or Vg / T_g crosses Qg_min or 1.01 Qg_min, the pair drops to third order and its embedded estimate
-             * no longer bounds the error.  Start and Euler-predicted end on different sides of a knee <=> sign bits differ. */
-            const double far = ref + (hh * AUG_KINK_REACH) * k[0][i];
-            if (i < 2)
-                kink |= (signbit(ref) != signbit(far)) | (signbit(ref - dgate) != signbit(far - dgate));
-            if (i == 2) {
-                const double invTg = 1.0 / p->T_g, dgq = 0.01 * p->Qg_min;
-                const double ug = ref * invTg - p->Qg_min, up = far * invTg - p->Qg_min;
-                kink_gw = (signbit(ug) != signbit(up)) | (signbit(ug - dgq) != signbit(up - dgq));
-                /* a soil box that starts to drain within the step can lift Vg through its gate within the same step, which
-                 * the predictor (slope at the step's start: -Qg) cannot see: a step across a soil knee while Vg / T_g is
-                 * below the upper knee of its gate counts as crossing that too */
-                kink_gw |= kink & (signbit(ug - dgq) != 0);
-            }
         }
         if (kink_gw) err *= targeted ? AUG_KNEE_GW : AUG_KINK_GW;     /* a crossing the first slope did not announce: accepted only if short */
         else if (kink && !targeted) err *= AUG_KINK_SOIL;            /* (a step that ends at a soil knee: no inflation) */

@@ -377,6 +377,7 @@ struct SysAug {
     // (A step aimed at a knee of the groundwater gate keeps a factor KNEE_GW: where the first slope misjudges the crossing
     // time the knee sits well inside the step, and that gate does not forgive it -- one member-day of the 100 000 at 1.5e-6.)
     static constexpr double KNEE_LO = 0.02, KNEE_HI = 0.9, KNEE_OVER = 1.05, KNEE_GW = 10.0;
+    static constexpr double DAY_START = 0.2;
     static constexpr double AUX_WEIGHT = 3.0;
     // z[9] carries cQ * Qr**b_Q (the factor the flow equation multiplies it with, folded into the state: one multiplication
     // less per right-hand side; its ODE is linear in it, so the scaling changes nothing else)
@@ -533,6 +534,9 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     SP_KEEP_SCALAR(huge); SP_KEEP_SCALAR(c11);
 #undef SP_KEEP_SCALAR
     R t = 0, h = (R)h_carry;
+    // (the step size carried over the day boundary belongs to the smooth end of a day; the forcing jumps at midnight, and the
+    // first attempt of the new day with it was rejected on 85 % of the member-days: SYS::DAY_START of it is the better guess)
+    if constexpr (SYS::KINK_AWARE) h *= (R)SYS::DAY_START;
     if (!(h > (R)0) || h > T) h = T;
     // attempts made today by every lane that is still alive: lanes attempt in lockstep (one attempt per trip of the loop
     // below for everyone who has not finished), so one wave-uniform counter serves them all -- and the step cap and the
@@ -576,9 +580,10 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = b1 * kq[i]; if (SYS::QUAD_IN_NORM) eq[i] = e1 * kq[i]; }
         bool targeted = false;
+        R kfac = (R)1;       // factor on the error estimate of a step that crosses a knee of a gate (SYS::KINK_AWARE)
         if constexpr (SYS::KINK_AWARE) {
-            // time to the nearest knee of a gate along the first slope (SYS::KNEE_*): a knee inside the step ends the step
-            R hk = huge;
+            // times to the knees of the gates along the first slope (SYS::KNEE_*, KINK_*): soil boxes (hs), groundwater (hg)
+            R hs = huge, hg = huge, ugd = 0;
             const R tlo = (R)SYS::KNEE_LO * hh;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -586,12 +591,24 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 const R sl = (i < 2) ? k1[i] : k1[2] * c.invTg;
                 const R gd = (i < 2) ? c.dgate : c.dgq;
                 const R r = sp_rcp_fast(sl);
-                const R t0 = ((R)0 - g) * r, t1 = (gd - g) * r;
-                hk = sp_min_raw(hk, sp_min_raw(sp_if_above(t0, tlo), sp_if_above(t1, tlo)));
+                const R gdg = gd - g;
+                const R t0 = ((R)0 - g) * r, t1 = gdg * r;
+                const R tn = sp_min_raw(sp_if_above(t0, tlo), sp_if_above(t1, tlo));
+                if (i < 2) hs = sp_min_raw(hs, tn); else { hg = tn; ugd = gdg; }
             }
-            const R hcut = hk * (R)SYS::KNEE_OVER;
+            // a knee inside the step ends the step just past it
+            const R hcut = sp_min_raw(hs, hg) * (R)SYS::KNEE_OVER;
             targeted = alive && !last_chance && hcut < (R)SYS::KNEE_HI * hh;
             hh = targeted ? hcut : hh;
+            // a knee within KINK_REACH x the step along the first slope (a step that, by its first slope, stops just short of a
+            // knee may well cross it) that the step was not aimed at: its estimate is not trusted.  A soil box that starts to
+            // drain within the step can lift Vg through its gate within the same step, which the slope at the step's start
+            // (dVg/dt = -Qg there) cannot see: a soil knee within reach while Vg / T_g is below the upper knee of its gate
+            // (gd - g > 0) counts as a groundwater knee too.  A step aimed at a groundwater knee keeps KNEE_GW.
+            const R look = (R)SYS::KINK_REACH * hh;
+            const bool cs = hs < look, cg = hg < look;
+            const bool gw = cg || (cs && ugd > (R)0);
+            kfac = gw ? (targeted ? (R)SYS::KNEE_GW : (R)SYS::KINK_GW) : ((cs && !targeted) ? (R)SYS::KINK_SOIL : (R)1);
         }
         {
             const R h21 = hh * a21;
@@ -639,9 +656,6 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         // embedded error estimate and scaled error norm.  The scale uses the Euler predictor y + h k1 for "the new value":
         // the 5th-order increment itself is only formed once the step is accepted (weights premultiplied by the accept mask).
         R err = 0, chk = 0;
-        int kink = 0, kink_gw = 0;               // sign bit set: the step crosses a knee of a soil / the groundwater gate (SYS::KINK_AWARE)
-        R hfar = hh;
-        if constexpr (SYS::KINK_AWARE) hfar = hh * (R)SYS::KINK_REACH;
         R dq[4];
         const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
 #pragma unroll
@@ -657,22 +671,6 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 if constexpr (SYS::SOIL_REL) { if (i < 2) w = sp_max(w, c.dgate); }
                 const R sc = sp_fma(rtol, w, atol);
                 err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
-                if constexpr (SYS::KINK_AWARE) {
-                    // start and predicted end on different sides of a knee of the gate <=> the sign bits differ.  The end is
-                    // predicted KINK_REACH x the Euler displacement ahead: a step that, by its first slope, stops just short
-                    // of a knee may well cross it.
-                    const R far = sp_fma(hfar, k1[i], ref);
-                    if (i < 2) kink |= sp_sign_xor(ref, far) | sp_sign_xor(ref - c.dgate, far - c.dgate);
-                    if (i == 2) {
-                        const R ug = sp_fma(ref, c.invTg, -c.Qgmin), up = sp_fma(far, c.invTg, -c.Qgmin);
-                        const R ugd = ug - c.dgq;
-                        kink_gw = sp_sign_xor(ug, up) | sp_sign_xor(ugd, up - c.dgq);
-                        // A soil box that starts to drain within the step can lift Vg through its gate within the same step,
-                        // which a predictor from the slope at the step's start (dVg/dt = -Qg there) cannot see: a step that
-                        // crosses a soil knee while Vg / T_g is below the upper knee of its gate counts as crossing that too.
-                        kink_gw |= kink & sp_sign_xor(ugd, (R)0);
-                    }
-                }
             }
         }
         if constexpr (SYS::KINK_AWARE) {
@@ -680,7 +678,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
             const R he = sp_fma(he1, k1[10], sp_fma(he3, k3[10], sp_fma(he4, k4[10], sp_fma(he5, k5[10], he6 * k6[10]))));
             const R sc = sp_fma(rtol_aux, sp_absmax(y[10], sp_fma(hh, k1[10], y[10])), atol_aux);
             err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
-            err *= (kink_gw < 0) ? (targeted ? (R)SYS::KNEE_GW : (R)SYS::KINK_GW) : ((kink < 0 && !targeted) ? (R)SYS::KINK_SOIL : (R)1);
+            err *= kfac;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -916,7 +914,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
     R huge = sp_huge<R>(), c11 = (R)1.1;
     SP_KEEP_SCALAR(huge); SP_KEEP_SCALAR(c11);
 #undef SP_KEEP_SCALAR
-    R t = 0, h = (R)h_carry;
+    R t = 0, h = (R)h_carry * SysAug::DAY_START;
     if (!(h > (R)0) || h > T) h = T;
     int trip = 0;
     unsigned n_alive = 0, n_acc = 0;
@@ -955,18 +953,29 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         quad_rhs(y, k, j_lt2, j_eq2, k1, kq);
         sq = b1 * kq;
         bool targeted = false;
+        R kfac = 1.0;
         {
-            // time to the nearest knee along the first slope, as in ck_day<SysAug>: this lane's gate, then the quad's minimum
+            // times to the knees along the first slope, as in ck_day<SysAug>: this lane's gate, then the quad's minimum
             const R tlo = SysAug::KNEE_LO * hh;
             const R g = sp_fma(y[0] - k.eoff, k.gs, k.g0), sl = k1[0] * k.gs;
             const R r = sp_rcp_fast(sl);
-            const R t0 = (0.0 - g) * r, t1 = (k.gd - g) * r;
-            R hk = sp_min_raw(huge, sp_min_raw(sp_if_above(t0, tlo), sp_if_above(t1, tlo)));
+            const R gdg = k.gd - g;
+            const R t0 = (0.0 - g) * r, t1 = gdg * r;
+            const R tn = sp_min_raw(sp_if_above(t0, tlo), sp_if_above(t1, tlo));
+            R hk = sp_min_raw(huge, tn);
             hk = sp_min_raw(hk, quad_perm<SP_QP(1, 0, 3, 2)>(hk));
             hk = sp_min_raw(hk, quad_perm<SP_QP(2, 3, 0, 1)>(hk));
             const R hcut = hk * SysAug::KNEE_OVER;
             targeted = alive && !last_chance && hcut < SysAug::KNEE_HI * hh;
             hh = targeted ? hcut : hh;
+            // what the lanes of the quad see within KINK_REACH x the step (1: a soil knee, 2: a groundwater knee, 4: Vg / T_g
+            // below the upper knee of its gate), OR-ed; then the one-lane kernel's choice of factor
+            const R look = SysAug::KINK_REACH * hh;
+            int kink = (tn < look ? k.kbit : 0) | (gdg > 0.0 ? k.lowbit : 0);
+            kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(1, 0, 3, 2), 0xf, 0xf, true);
+            kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(2, 3, 0, 1), 0xf, 0xf, true);
+            const bool gw = (kink & 2) != 0 || (kink & 5) == 5;
+            kfac = gw ? (targeted ? SysAug::KNEE_GW : SysAug::KINK_GW) : (((kink & 1) && !targeted) ? SysAug::KINK_SOIL : 1.0);
         }
         {
             const R h21 = hh * a21;
@@ -1011,7 +1020,6 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         // states (Qr, Msus, TDPr, PPr), as ck_day<SysAug>'s `chk` does: a non-finite one makes the lane's error infinite.
         const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
         R err = 0;
-        int kink = 0;
         R he_s[3];
 #pragma unroll
         for (int i = 0; i < 3; i += 2) {
@@ -1024,11 +1032,6 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
             if (i == 0) w = sp_max(w, k.efloor);
             const R sc = sp_fma(rtol, w, atol);
             err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
-            if (i == 0) {      // knee test of this lane's gate, as ck_day<SysAug> does for components 0, 1, 2
-                const R g = sp_fma(ref, k.gs, k.g0), gp = sp_fma(sp_fma(hh * SysAug::KINK_REACH, k1[0], ref), k.gs, k.g0);
-                const R gd = g - k.gd;
-                kink = ((sp_sign_xor(g, gp) | sp_sign_xor(gd, gp - k.gd)) < 0 ? k.kbit : 0) | (sp_sign_xor(gd, (R)0) < 0 ? k.lowbit : 0);
-            }
         }
         {
             // Qr**k_M (slot 1 of the groundwater lane) in the norm at AUX_WEIGHT x the tolerance; x 0 on the other lanes
@@ -1042,13 +1045,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         }
         err = sp_max(err, quad_perm<SP_QP(1, 0, 3, 2)>(err));
         err = sp_max(err, quad_perm<SP_QP(2, 3, 0, 1)>(err));
-        {
-            // what the lanes of the quad saw, OR-ed; then the one-lane kernel's choice of factor
-            kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(1, 0, 3, 2), 0xf, 0xf, true);
-            kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(2, 3, 0, 1), 0xf, 0xf, true);
-            const bool gw = (kink & 2) != 0 || (kink & 5) == 5;
-            err *= gw ? (targeted ? SysAug::KNEE_GW : SysAug::KINK_GW) : (((kink & 1) && !targeted) ? SysAug::KINK_SOIL : 1.0);
-        }
+        err *= kfac;
         R dq = hh * sq;
         const bool bad = !(err < huge);
 
