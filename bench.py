@@ -44,9 +44,9 @@ PCIE_SPEC_GBS = 63.0             # PCIe Gen5 x16, same guide
 FP64_FMA_MEASURED_TFLOPS = 1024 * 128 / 2.36e-9 / 1e12
 # fp64 operations of one Cash-Karp attempt of one member on the augmented system (6 right-hand sides + stage sums + error
 # norm + knee targeting and knee test + update), counted in the gfx950 ISA of simplyp_queue_kernel<2,false,1>'s attempt loop
-# (common path: 878 instructions, tools/isa_stats.py): 403 FMAs (x2) + 209 mul + 63 add + 27 max/min + 17 rcp = 719 fp64
+# (common path: 854 instructions, tools/isa_stats.py): 399 FMAs (x2) + 209 mul + 57 add + 27 max/min + 17 rcp = 709 fp64
 # instructions (Roofline)
-FLOPS_PER_ATTEMPT = 2 * 403 + 209 + 63 + 27 + 17
+FLOPS_PER_ATTEMPT = 2 * 399 + 209 + 57 + 27 + 17
 
 # BASELINE.json's configurations.  bytes_per_cd: algorithmic HBM bytes per catchment-day of the
 # config's output mode -- FULL = 25 outputs x 8 B + 2 forcing values x 8 B; REACH-5 = 5 x 8 + 16; annual sums = 16 B of

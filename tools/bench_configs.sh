@@ -1,6 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out/r02_cfg
-bash tools/profile_bench.sh r02_knee_c2 --config c2 > gpurun_out/r02_cfg/profile_c2.log 2>&1; tail -2 gpurun_out/r02_cfg/profile_c2.log
+# (C2 is profiled by tools/final_round.sh)
 timeout -k 10 300 python bench.py --config c5 --steps 3 --warmup 1 > gpurun_out/r02_cfg/bench_c5.json 2> gpurun_out/r02_cfg/bench_c5.err
 for n in 12500 25000 50000; do timeout -k 10 300 python bench.py --members $n --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r02_cfg/bench_c3_shard_$n.json 2> gpurun_out/r02_cfg/shard_$n.err; done
 timeout -k 10 200 python tools/time_dropin.py > gpurun_out/r02_cfg/dropin.log 2>&1; cat gpurun_out/r02_cfg/dropin.log

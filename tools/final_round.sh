@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r02_fin
-python -m pytest tests -m gpu -q > gpurun_out/r02_fin/gputests.log 2>&1; tail -3 gpurun_out/r02_fin/gputests.log
+if [ "$1" != notests ]; then python -m pytest tests -m gpu -q > gpurun_out/r02_fin/gputests.log 2>&1; tail -3 gpurun_out/r02_fin/gputests.log; fi
 bash tools/profile_bench.sh r02_knee > gpurun_out/r02_fin/profile_c3.log 2>&1; tail -1 gpurun_out/r02_fin/profile_c3.log
 bash tools/profile_bench.sh r02_knee_c2 --config c2 > gpurun_out/r02_fin/profile_c2.log 2>&1; tail -1 gpurun_out/r02_fin/profile_c2.log
 timeout -k 10 300 python bench.py --config c5 --steps 3 --warmup 1 > gpurun_out/r02_fin/bench_c5.json 2> gpurun_out/r02_fin/bench_c5.err

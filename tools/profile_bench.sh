@@ -9,13 +9,19 @@ EXTRA="$@"
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+Q="--no-cpu-baseline --no-parity"
+if [ -z "$ONLY_TRACE" ]; then
 python3 bench.py --steps 5 --warmup 1 $EXTRA > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
-Q="--no-cpu-baseline --no-parity"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 $Q $EXTRA > $OUT/bench_trace.json 2> $OUT/trace.err
+fi
+# the traced passes leave the table in HBM: under the profiler the streamed chunk copies sometimes run as shader blits that share
+# the CUs with the persistent kernel (seen: kernel 932 ms instead of 538, copies keeping pace) -- not what an unprofiled run does
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 4 --warmup 1 --no-stream $Q $EXTRA > $OUT/bench_trace.json 2> $OUT/trace.err
+if [ -z "$ONLY_TRACE" ]; then
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-stream $Q $EXTRA > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-stream $Q $EXTRA > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --no-stream $Q $EXTRA > /dev/null 2> $OUT/pmc_sq.err || true
+fi
 # keep only the small summaries (traces of torch's own kernels can be large)
 for f in $(find $OUT -name "*kernel_stats.csv" -o -name "*counter_collection.csv" -o -name "*kernel_trace.csv"); do
   python3 - "$f" <<'PY'
