@@ -356,11 +356,12 @@ struct SysAug {
     // Steps across a knee of a gate.  f_x (model.py:23-37) is C1 only: where a soil box crosses fc or 1.01 fc, or Vg / T_g crosses
     // Qg_min or 1.01 Qg_min, the second derivative of the right-hand side jumps, a 5(4) pair drops to third order on the step
     // that straddles the knee and its embedded estimate no longer bounds the error (measured: the worst member-days of the
-    // 100 000-member bench ensemble were all such steps, 50 x above their tolerance).  A step whose start and Euler-predicted end
-    // lie on different sides of a knee therefore has its error estimate multiplied by KINK_SOIL / KINK_GW: it is accepted only if it is
-    // short.  With this, and Qr**k_M in the norm at AUX_WEIGHT x the tolerance (on a day when a nearly dry reach is wetted
-    // Qr**k_M grows 200-fold and its own truncation error showed in the sediment flux), the error at a given rtol drops 7-fold:
-    // rtol 1e-7 now gives what 1e-8 gave -- 90 instead of 126 right-hand sides per day (profiles/r02_experiments.md).
+    // 100 000-member bench ensemble were all such steps, 50 x above their tolerance).  A step that, along its first slope, has a
+    // knee within KINK_REACH x its length without having been aimed at it (below) therefore has its error estimate multiplied
+    // by KINK_SOIL / KINK_GW: it is accepted only if it is short.  With this, and Qr**k_M in the norm at AUX_WEIGHT x the
+    // tolerance (on a day when a nearly dry reach is wetted Qr**k_M grows 200-fold and its own truncation error showed in the
+    // sediment flux), the error at a given rtol drops 7-fold: rtol 1e-7 now gives what 1e-8 gave -- 84 instead of 126
+    // right-hand sides per catchment-day (profiles/r02_experiments.md).
     // (KINK_SOIL for the knees of the two soil-water gates, crossed on most wet days; KINK_GW for the groundwater gate, whose
     // zone is 1 % of Qg_min wide and is crossed a few times a year by members with a low Qg_min: with 10 there, 7 members of
     // the 100 000 still had a day at 5-9e-7)
@@ -373,7 +374,8 @@ struct SysAug {
     // few percent of the step, the pair keeps its order, no inflation is applied, and the next step starts on the far side.
     // The step size carried on is not reduced by such a cut.  Wave-level attempts per day on the bench ensemble 22.2 -> 18.7
     // (fewer rejections, and lanes that cross a knee no longer hold their wave for 2-3 extra attempts); inflation stays for
-    // crossings the first slope did not announce.
+    // knees in the step's last tenth or just beyond its end; knees within its first KNEE_LO are left alone (benign).
+    // DAY_START: a day starts with this share of the step size carried over midnight (see ck_day).
     // (A step aimed at a knee of the groundwater gate keeps a factor KNEE_GW: where the first slope misjudges the crossing
     // time the knee sits well inside the step, and that gate does not forgive it -- one member-day of the 100 000 at 1.5e-6.)
     static constexpr double KNEE_LO = 0.02, KNEE_HI = 0.9, KNEE_OVER = 1.05, KNEE_GW = 10.0;
