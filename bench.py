@@ -4,22 +4,29 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4|c5] [--scaling weak|strong]
 
 Default workload (config.workload): BASELINE.json's Tarland Monte-Carlo parameter ensemble (config C3): the shipped
-Tarland workbook + 30-year daily met series (1981-2010, 10 957 days, 1 sub-catchment, Dynamic_EPC0 = 'y'),
-100 000 members per GPU drawn from SURVEY.md section 8(d)'s distribution, the five documented reach outputs written
-daily ("REACH-5": Vr, Qr and the three daily fluxes), fp64, default solver (Cash-Karp 5(4) with a step controller that
-knows the knees of the reference's smooth-step gates, rtol 1e-7: the setting that meets the <= 1e-6 parity bar against
-odeint(rtol=atol=1e-12) on every member of the ensemble).
+Tarland workbook + 30-year daily met series (1981-2010, 10 957 days, 1 sub-catchment, Dynamic_EPC0 = 'y'), ONE ensemble of
+100 000 members drawn from SURVEY.md section 8(d)'s distribution and sharded over the GPUs (1 -> 8), the five documented
+reach outputs written daily ("REACH-5": Vr, Qr and the three daily fluxes), fp64, default solver (Cash-Karp 5(4) with a
+step controller that knows the knees of the reference's smooth-step gates, rtol 1e-7: the setting that meets the <= 1e-6
+parity bar against odeint(rtol=atol=1e-12) on every member of the ensemble).
 
 A "step" is one pass of the whole ensemble through all days.  Inputs are resident in HBM before the timed region; the
 output table is DELIVERED TO PINNED HOST MEMORY inside it (the reference produces its values in host memory,
-model.py:644, :721-724): the library streams every finished 256-day chunk over PCIe on a second stream while later chunks
-compute (simplyp_stream_out), and the step ends when the last byte has arrived and rank 0 holds the per-member
-summaries.  `value` is that transfer-inclusive rate; `value_device_resident` (table left in HBM) and
-`value_h2d_inclusive` (plus the upload of the inputs) are reported beside it.
+model.py:644, :721-724): the library streams every finished 64-day chunk over PCIe on two further streams while later
+chunks compute (simplyp_stream_out), and the step ends when the last byte has arrived and rank 0 holds the per-member
+summaries.  `value` is that transfer-inclusive rate -- the same definition at every N: if the page-locked staging cannot be
+had the bench exits non-zero instead of quietly measuring something else (--no-stream asks for the device-resident rate
+explicitly).  `value_device_resident` (table left in HBM) and `value_h2d_inclusive` (plus the upload of the inputs) are
+reported beside it.
 
 Members shard across GPUs with no data-path collective (ensemble.run_sharded); the only exchange is the final gather of
-per-member summaries to rank 0 over RCCL.  --scaling weak (default): every rank brings its own `--members`; strong: one
-ensemble of `--members` split over the ranks.
+per-member summaries to rank 0 over RCCL.  --scaling: strong = one ensemble of `--members` split over the ranks (default for
+c3: BASELINE C3 is "a 100k-member ensemble sharded across 1 -> 8 GPUs"); weak = every rank brings its own `--members`
+(default for the other configs).  With the default strong C3 line at N > 1 the weak figure (100 000 members per GPU) is
+measured after the timed region and carried in the same line as `value_weak`.
+
+After the timed region of the default run the line also gets `secondary`: BASELINE configs C2 and C5 and a C3 pass that
+leaves only the members' goodness-of-fit table (simplyp_gof), a few passes each, so that the driver's run sees them.
 
 With --gpus N > 1 from a plain shell the script starts its own N ranks (torch.distributed.run) before anything touches
 the GPU and relays rank 0's line.  Prints ONE JSON line on rank 0.
@@ -52,17 +59,17 @@ FLOPS_PER_ATTEMPT = 2 * 399 + 209 + 57 + 27 + 17
 # config's output mode -- FULL = 25 outputs x 8 B + 2 forcing values x 8 B; REACH-5 = 5 x 8 + 16; annual sums = 16 B of
 # forcing + 4 columns x 8 B x 30 rows / 10 957 days.
 CONFIGS = {
-    'c3': dict(members=100000, bytes_per_cd=56.0, dtype='f64', out='REACH-5 daily', parity_grade=True,
+    'c3': dict(members=100000, bytes_per_cd=56.0, dtype='f64', out='REACH-5 daily', parity_grade=True, scaling='strong',
                what="Tarland Monte-Carlo parameter ensemble (BASELINE config C3): 1 sub-catchment, 2 land-use soil boxes, "
                     "30-yr daily 1981-2010 (10957 d), Cash-Karp 5(4) on the augmented system, rtol=%(rtol)g"),
-    'c2': dict(members=1024, bytes_per_cd=216.0, dtype='f64', out='FULL 25 columns daily', parity_grade=True,
+    'c2': dict(members=1024, bytes_per_cd=216.0, dtype='f64', out='FULL 25 columns daily', parity_grade=True, scaling='weak',
                what="Tarland full catchment, replicated-parameter ensemble (BASELINE config C2): 1 sub-catchment, 30-yr daily "
                     "1981-2010 (10957 d), all 25 output columns, Cash-Karp 5(4) on the augmented system, rtol=%(rtol)g"),
-    'c4': dict(members=10000, bytes_per_cd=56.0, dtype='f64', out='REACH-5 daily of the outlet reach', parity_grade=True,
+    'c4': dict(members=10000, bytes_per_cd=56.0, dtype='f64', out='REACH-5 daily of the outlet reach', parity_grade=True, scaling='weak',
                what="synthetic 256-reach chain x 4 land-use classes, 50-yr daily (18262 d), reach-chain routing in-kernel "
                     "(BASELINE config C4), Cash-Karp 5(4) on the augmented system, rtol=%(rtol)g"),
     'c5': dict(members=125000, bytes_per_cd=16.0 + 4 * 8 * 30 / 10957.0, dtype='f32+f64', out='annual sums of the 4 fluxes',
-               parity_grade=False,
+               parity_grade=False, scaling='weak',
                what="one GPU's share of the 1M-member Tarland ensemble (BASELINE config C5): fp32 Runge-Kutta stages + fp64 "
                     "daily integrals / soil P / carried state, rtol=%(rtol)g, output = 30 annual sums of Qr and the 3 fluxes"),
 }
@@ -74,16 +81,19 @@ def parse_args(argv=None):
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='c3')
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default=None,
+                    help="default: strong for c3 (BASELINE C3 = one 100k-member ensemble sharded over the GPUs), weak otherwise")
     ap.add_argument('--members', type=int, default=None,
                     help='members per GPU (weak) or in the whole ensemble (strong); default: the config\'s size')
     ap.add_argument('--reaches', type=int, default=256, help='c4 only')
     ap.add_argument('--days', type=int, default=None, help='c4 only (default 18262)')
     ap.add_argument('--rtol', type=float, default=None, help='override the config\'s solver tolerance (experiments)')
     ap.add_argument('--chunk-days', type=int, default=None, help='opts.time_chunk_days (experiments; default: the library chooses)')
+    ap.add_argument('--lanes-per-member', type=int, default=None, help='opts.lanes_per_member (experiments; default: the library chooses)')
     ap.add_argument('--no-stream', action='store_true', help='leave the output table in HBM (value = device-resident rate)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the accuracy checks (keeps a profile to one kernel shape)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary legs (c2, c5, c3 -> goodness of fit only, value_weak)')
     return ap.parse_args(argv)
 
 
@@ -117,7 +127,8 @@ def kernel_source_hash():
     measured on."""
     h = hashlib.sha256()
     for rel in ('simplyp_amd/csrc/simplyp_kernels.hip.h', 'simplyp_amd/csrc/simplyp_hip.hip',
-                'simplyp_amd/csrc/simplyp_gof.hip.h', 'simplyp_amd/csrc/simplyp_waterbody.hip.h', 'include/simplyp.h'):
+                'simplyp_amd/csrc/simplyp_gof.hip.h', 'simplyp_amd/csrc/simplyp_waterbody.hip.h', 'include/simplyp.h',
+                'include/simplyp_controller.h'):
         with open(os.path.join(ROOT, rel), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -148,14 +159,214 @@ def build_problem(cfg, n_members, seed_offset, args):
         pr['opts'].rtol = args.rtol
     if args.chunk_days is not None:
         pr['opts'].time_chunk_days = args.chunk_days
+    if args.lanes_per_member is not None:
+        pr['opts'].lanes_per_member = args.lanes_per_member
     pr.setdefault('out_reaches', None)
     pr.setdefault('period_of_day', None)
     return pr
 
 
+class Bench(object):
+    """The process-wide pieces every leg shares: rank, process group, engine, the stream the passes run on."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.args = args
+        self.torch, self.dist = torch, dist
+        self.t_start = time.perf_counter()
+        self.rank = int(os.environ.get('RANK', '0'))
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        # one rank per GPU; SIMPLYP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+        self.backend = os.environ.get('SIMPLYP_BENCH_BACKEND', 'nccl')
+        n_dev = torch.cuda.device_count()
+        if self.backend == 'gloo':
+            local_rank = local_rank % max(n_dev, 1)
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        if self.world > 1:
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            if self.backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            else:
+                dist.init_process_group(self.backend)
+        from simplyp_amd import engine
+        # staging buffers next to the GPU's PCIe root: page-locked memory is placed by first touch, and a 44 GB buffer on the
+        # other socket costs a fifth of the D2H rate (44.8 instead of 55.9 GB/s: tools/probe_d2h_numa.py) -- also with one rank,
+        # which the scheduler may have started on either socket.  The binding is undone before the CPU baseline runs.
+        try:
+            self.affinity0 = os.sched_getaffinity(0)
+        except (AttributeError, OSError):
+            self.affinity0 = None
+        self.numa_node = engine.bind_host_thread_to_gpu_numa_node(local_rank)
+        self.eng = engine.get_engine(local_rank)
+        self.stream = torch.cuda.Stream(device=self.eng.tdev)
+        self.coll_dev = self.eng.tdev if self.backend == 'nccl' else 'cpu'
+
+    def restore_affinity(self):
+        if self.affinity0:
+            try:
+                os.sched_setaffinity(0, self.affinity0)
+            except OSError:
+                pass
+
+    def progress(self, msg):          # long configurations (c4: ~80 s per pass) must show signs of life on stderr
+        if self.rank == 0:
+            print("[bench %s] %s (%.0f s)" % (self.args.config, msg, time.perf_counter() - self.t_start), file=sys.stderr, flush=True)
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def all_min(self, flag):
+        if self.world == 1:
+            return bool(flag)
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def all_max(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def per_rank(self, x):
+        """one float per rank, on every rank"""
+        if self.world == 1:
+            return [float(x)]
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.coll_dev)
+        parts = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [float(p.item()) for p in parts]
+
+
+class Leg(object):
+    """One workload on this rank's GPU: problem, device inputs, output table (+ pinned host copy), timed passes."""
+
+    def __init__(self, b, config, scaling, n_arg, stream, seed_base=0):
+        import numpy as np
+        from simplyp_amd import engine, ensemble
+        torch = b.torch
+        self.b, self.config, self.scaling, self.n_arg = b, config, scaling, n_arg
+        self.cfg = CONFIGS[config]
+        world, rank = b.world, b.rank
+        if scaling == 'weak':
+            self.e_local, self.e_total = n_arg, n_arg * world
+            self.prob = build_problem(config, self.e_local, seed_base + rank, b.args)
+        else:
+            self.e_total = n_arg
+            lo, hi = ensemble.shard_bounds(self.e_total, world, rank)
+            self.e_local = hi - lo
+            self.prob = build_problem(config, self.e_total, seed_base, b.args)          # the same ensemble on every rank; run_sharded slices it
+        prob = self.prob
+        self.opts = prob['opts']
+        self.D = prob['forcing'].shape[2]
+        self.S = prob['reach_params'].shape[1]
+        self.n_or = self.S if prob['out_reaches'] is None else len(prob['out_reaches'])
+        self.ncols = bin(self.opts.out_mask).count('1')
+        self.rows = self.opts.n_periods if self.opts.n_periods > 0 else self.D
+        eng = b.eng
+        # inputs: marshalled into pinned host arrays, uploaded once (resident in HBM before the timed region)
+        pinned = {}
+        for k in ('forcing', 'doy', 'member_params', 'reach_params'):
+            pinned[k] = engine.pinned_empty(prob[k].shape, prob[k].dtype)
+            pinned[k][...] = prob[k]
+
+        def upload():
+            t = [torch.from_numpy(pinned[k]).to(eng.tdev, non_blocking=True) for k in ('forcing', 'doy', 'member_params', 'reach_params')]
+            torch.cuda.synchronize()
+            return t
+        upload()
+        t0 = time.perf_counter()
+        self.dev = upload()
+        self.h2d_s = time.perf_counter() - t0
+        self.pod = None if prob['period_of_day'] is None else eng.to_device(prob['period_of_day'])
+        shape = (self.ncols, self.rows, self.n_or, self.e_local)
+        self.out = torch.empty(shape, dtype=torch.float64, device=eng.tdev)
+        self.out_bytes = self.out.numel() * 8
+        self.host_out, self.stream_note = None, None
+        if stream:
+            # every rank of the node page-locks its own copy of its table: more than 60 % of what the host has available is not
+            # attempted (a node that starts swapping or OOM-kills a rank measures nothing)
+            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+            avail = host_mem_available()
+            if avail is not None and self.out_bytes * local_world > 0.6 * avail:
+                self.stream_note = ("%d ranks x %.1f GB of pinned staging exceed 60 %% of the host's available memory (%.0f GB)"
+                                    % (local_world, self.out_bytes / 1e9, avail / 1e9))
+            else:
+                try:
+                    self.host_out = engine.pinned_empty(shape, np.float64)
+                except engine.EngineError as ex:          # not enough lockable host memory on this node
+                    self.stream_note = "pinned host buffer of %.1f GB not available (%s)" % (self.out_bytes / 1e9, ex)
+            # all ranks or none: the passes contain collectives, so the ranks must agree on what they run
+            if not b.all_min(self.host_out is not None):
+                if self.host_out is not None:
+                    self.stream_note = "another rank could not page-lock its staging buffer"
+                self.host_out = None
+
+    def free(self):
+        self.out = None
+        self.host_out = None
+        self.dev = None
+        self.b.torch.cuda.empty_cache()
+
+    def one_step(self, host):
+        from simplyp_amd import ensemble
+        b, prob, torch = self.b, self.prob, self.b.torch
+        weak = self.scaling == 'weak'
+
+        def run_fn(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=None, out_reaches=None, host=None):
+            return b.eng.run(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=forcing_of_member,
+                             out_reaches=out_reaches, out=self.out, period_of_day=self.pod, host_out=host, defer_sync=True)
+
+        # the pass runs on a torch stream of its own: the library launches on it, and the per-member summaries enqueued behind
+        # the kernel (ensemble.run_sharded) run beside the tail of the streamed copies instead of after it
+        with torch.cuda.stream(b.stream):
+            r = ensemble.run_sharded(run_fn, self.dev[0], self.dev[1], self.dev[2], self.dev[3], prob['up_ptr'], prob['up_idx'],
+                                     self.opts, out_reaches=prob['out_reaches'], sharded_inputs=weak,
+                                     total_members=self.e_total if weak else None,
+                                     member_counts=[self.e_local] * b.world if weak else None, host=host)
+        b.stream.synchronize()
+        return r
+
+    def timed(self, n_steps, host, what=None):
+        b = self.b
+        b.fence()
+        t_begin = time.perf_counter()
+        res_, st_ = None, []
+        for _ in range(n_steps):
+            if what:
+                b.progress(what)
+            res_ = self.one_step(host)
+            st_.append(res_['stats'])
+        b.fence()
+        dt = b.all_max(time.perf_counter() - t_begin)
+        return dt, res_, st_
+
+    @property
+    def cd_per_step(self):
+        return float(self.e_total) * self.S * self.D
+
+    @property
+    def cd_rank(self):
+        return float(self.e_local) * self.S * self.D
+
+    def kernel_name(self, stats):
+        return "simplyp_%s_kernel<%d, false, %d>" % ("queue" if stats.get('queued') else "chain", self.opts.integrator,
+                                                     int(stats.get('lanes_per_member', 1) or 1))
+
+    def roofline_frac(self, k_ms):
+        return self.cfg['bytes_per_cd'] * self.cd_rank / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+
 def main():
     args = parse_args()
-    t_start = time.perf_counter()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
 
@@ -163,153 +374,56 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    # one rank per GPU; SIMPLYP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
-    backend = os.environ.get('SIMPLYP_BENCH_BACKEND', 'nccl')
-    n_dev = torch.cuda.device_count()
-    if backend == 'gloo':
-        local_rank = local_rank % max(n_dev, 1)
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    from simplyp_amd import engine, ensemble, marshal
+    b = Bench(args)
+    rank, world, backend = b.rank, b.world, b.backend
+    from simplyp_amd import marshal
 
     cfg = CONFIGS[args.config]
+    scaling = args.scaling or cfg['scaling']
     n_arg = args.members if args.members is not None else cfg['members']
-    if args.scaling == 'weak':
-        e_local, e_total = n_arg, n_arg * world
-        prob = build_problem(args.config, e_local, rank, args)
-    else:
-        e_total = n_arg
-        lo, hi = ensemble.shard_bounds(e_total, world, rank)
-        e_local = hi - lo
-        prob = build_problem(args.config, e_total, 0, args)          # the same ensemble on every rank; run_sharded slices it
-    opts = prob['opts']
-    D = prob['forcing'].shape[2]
-    S = prob['reach_params'].shape[1]
-    n_or = S if prob['out_reaches'] is None else len(prob['out_reaches'])
-    ncols = bin(opts.out_mask).count('1')
-    rows = opts.n_periods if opts.n_periods > 0 else D
-
-    # staging buffers next to the GPU's PCIe root: page-locked memory is placed by first touch, and a 44 GB buffer on the other
-    # socket costs a fifth of the D2H rate (44.8 instead of 55.9 GB/s: tools/probe_d2h_numa.py) -- also with one rank, which the
-    # scheduler may have started on either socket
-    numa_node = engine.bind_host_thread_to_gpu_numa_node(local_rank)
-    eng = engine.get_engine(local_rank)
-    # inputs: marshalled into pinned host arrays, uploaded once (resident in HBM before the timed region)
-    pinned = {}
-    for k in ('forcing', 'doy', 'member_params', 'reach_params'):
-        pinned[k] = engine.pinned_empty(prob[k].shape, prob[k].dtype)
-        pinned[k][...] = prob[k]
-
-    def upload():
-        t = [torch.from_numpy(pinned[k]).to(eng.tdev, non_blocking=True) for k in ('forcing', 'doy', 'member_params', 'reach_params')]
-        torch.cuda.synchronize()
-        return t
-    upload()
-    t0 = time.perf_counter()
-    dev = upload()
-    h2d_s = time.perf_counter() - t0
-    pod = None if prob['period_of_day'] is None else eng.to_device(prob['period_of_day'])
-
-    out = torch.empty((ncols, rows, n_or, e_local), dtype=torch.float64, device=eng.tdev)
-    out_bytes = out.numel() * 8
-    host_out = None
-    stream_note = None
-    if not args.no_stream:
-        # every rank of the node page-locks its own copy of its table: refuse up front when that would take more than 60 % of
-        # what the host has available (a node that starts swapping or OOM-kills a rank measures nothing)
-        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
-        avail = host_mem_available()
-        if avail is not None and out_bytes * local_world > 0.6 * avail:
-            stream_note = ("%d ranks x %.1f GB of pinned staging exceed 60 %% of the host's available memory (%.0f GB): table left "
-                           "in HBM" % (local_world, out_bytes / 1e9, avail / 1e9))
-        else:
-            try:
-                host_out = engine.pinned_empty((ncols, rows, n_or, e_local), np.float64)
-            except engine.EngineError as ex:          # not enough lockable host memory on this node
-                stream_note = "pinned host buffer of %.1f GB not available (%s): table left in HBM" % (out_bytes / 1e9, ex)
-
-    if world > 1 and not args.no_stream:
-        # all ranks or none: the legs below contain collectives, so the ranks must agree on which legs they run
-        ok = torch.tensor([1 if host_out is not None else 0], dtype=torch.int32, device=eng.tdev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and host_out is not None:
-            host_out = None
-            stream_note = "another rank could not page-lock its staging buffer: table left in HBM on every rank"
-
-    # the pass runs on a torch stream of its own: the library launches on it, and the per-member summaries enqueued behind the
-    # kernel (ensemble.run_sharded) run beside the tail of the streamed copies instead of after it
-    bench_stream = torch.cuda.Stream(device=eng.tdev)
-
-    def run_fn(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=None, out_reaches=None, host=None):
-        return eng.run(forcing, doy, mp, rp, up_ptr, up_idx, o, forcing_of_member=forcing_of_member,
-                       out_reaches=out_reaches, out=out, period_of_day=pod, host_out=host, defer_sync=True)
-
-    def progress(msg):          # long configurations (c4: ~90 s per pass) must show signs of life on stderr
+    leg = Leg(b, args.config, scaling, n_arg, stream=not args.no_stream)
+    if not args.no_stream and leg.host_out is None:
+        # never a silent change of what `value` means: the N = 1 line is the table in pinned host memory, so is every other
         if rank == 0:
-            print("[bench %s] %s (%.0f s)" % (args.config, msg, time.perf_counter() - t_start), file=sys.stderr, flush=True)
-
-    def one_step(host):
-        progress("pass: %s" % ("streamed to host" if host is not None else "device-resident"))
-        with torch.cuda.stream(bench_stream):
-            r = ensemble.run_sharded(run_fn, dev[0], dev[1], dev[2], dev[3], prob['up_ptr'], prob['up_idx'], opts,
-                                     out_reaches=prob['out_reaches'], sharded_inputs=(args.scaling == 'weak'),
-                                     total_members=e_total if args.scaling == 'weak' else None,
-                                     member_counts=[e_local] * world if args.scaling == 'weak' else None, host=host)
-        bench_stream.synchronize()
-        return r
-
-    def fence():
+            print("bench.py: %s -- `value` is defined with the table delivered to pinned host memory; run with --no-stream to "
+                  "measure the device-resident rate instead" % leg.stream_note, file=sys.stderr, flush=True)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            dist.destroy_process_group()
+        raise SystemExit(3)
+    opts, D, S, e_local, e_total = leg.opts, leg.D, leg.S, leg.e_local, leg.e_total
+    host_out, out = leg.host_out, leg.out
 
-    def timed(n_steps, host):
-        fence()
-        t_begin = time.perf_counter()
-        res_, st_ = None, []
-        for _ in range(n_steps):
-            res_ = one_step(host)
-            st_.append(res_['stats'])
-        fence()
-        dt = time.perf_counter() - t_begin
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.tdev if backend == 'nccl' else 'cpu')
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), res_, st_
+    def what(h):
+        return "pass: %s" % ("streamed to host" if h is not None else "device-resident")
 
     for _ in range(args.warmup):
-        one_step(host_out)
-    elapsed, res, step_stats = timed(args.steps, host_out)
+        b.progress(what(host_out))
+        leg.one_step(host_out)
+    elapsed, res, step_stats = leg.timed(args.steps, host_out, what(host_out))
     status, stats = res['status'], res['stats']
     n_bad = int((status != 0).sum().item())
+    k_ms = float(np.mean([s['kernel_ms'] for s in step_stats]))
+    k_ms_ranks = b.per_rank(k_ms)
+    wall_ms_ranks = b.per_rank(float(np.mean([s['wall_ms'] for s in step_stats])))
 
     # the device-resident rate beside it (same kernel, table left in HBM)
     elapsed_dev = None
+    n_dev_steps = max(1, min(args.steps, 3))
     if host_out is not None:
-        one_step(None)
-        elapsed_dev, _, _ = timed(max(1, min(args.steps, 3)), None)
+        leg.one_step(None)
+        elapsed_dev, _, _ = leg.timed(n_dev_steps, None, what(None))
         # leave a streamed run's table on both sides for the parity sample below
-        one_step(host_out)
+        leg.one_step(host_out)
         torch.cuda.synchronize()
 
+    line = None
     if rank == 0:
-        cd_per_step = float(e_total) * S * D
+        cd_per_step = leg.cd_per_step
         sec_per_step = elapsed / args.steps
         value = cd_per_step / sec_per_step
-        k_ms = float(np.mean([s['kernel_ms'] for s in step_stats]))
         rhs = step_stats[-1]['rhs_evals']
-        cd_rank = float(e_local) * S * D
+        cd_rank = leg.cd_rank
         alg_bytes = cfg['bytes_per_cd'] * cd_rank
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9                  # GB/s, this rank's launch
         khash = kernel_source_hash()
@@ -328,35 +442,37 @@ def main():
         line = {
             "metric": "catchment-days/sec (ensemble x reaches x days)", "value": value, "unit": "catchment-days/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": cfg['dtype'], "data": "synthetic",
-            "config": {"workload": "%s; %d members %s; output: %s" % (cfg['what'] % dict(rtol=opts.rtol), n_arg, "per GPU" if args.scaling == 'weak' else "in all, split over the GPUs", cfg['out']),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": cfg['dtype'], "data": "synthetic",
+            "config": {"workload": "%s; %d members %s; output: %s" % (cfg['what'] % dict(rtol=opts.rtol), n_arg, "per GPU" if scaling == 'weak' else "in all, split over the GPUs", cfg['out']),
                        "name": args.config, "members_per_gpu": e_local, "members_total": e_total, "reaches": S, "days": D,
                        "outputs": marshal.columns_of_mask(opts.out_mask),
                        "solver": {k: getattr(opts, k) for k in ('integrator', 'rtol', 'atol', 'project_vr')},
                        "parity_grade": cfg['parity_grade'],
                        "parallelism": "ensemble shards (ensemble.run_sharded), %d GPU(s), no data-path collective; final gather "
                                       "of per-member summaries over %s" % (world, 'RCCL' if backend == 'nccl' else backend)},
+            "members_total": e_total,
+            "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == 'nccl') else (1 if world == 1 else 0)),
+            "collective_backend": None if world == 1 else ('nccl (RCCL over xGMI)' if backend == 'nccl' else backend + ' (rehearsal: no RCCL in this run)'),
+            "per_rank": {"kernel_ms": [round(x, 3) for x in k_ms_ranks], "run_wall_ms": [round(x, 3) for x in wall_ms_ranks]},
             "value_includes": ("output table delivered to pinned host memory (streamed per time chunk beside the kernel) + "
                                "per-member summaries gathered on rank 0; inputs resident in HBM") if host_out is not None
-                              else "output table left in HBM + per-member summaries gathered on rank 0; inputs resident in HBM",
-            "value_device_resident": None if elapsed_dev is None else cd_per_step / (elapsed_dev / max(1, min(args.steps, 3))),
-            "value_h2d_inclusive": cd_per_step / (sec_per_step + h2d_s),
-            "transfer": {"out_bytes_per_gpu": out_bytes, "h2d_input_ms": h2d_s * 1e3,
+                              else "output table left in HBM (--no-stream) + per-member summaries gathered on rank 0; inputs resident in HBM",
+            "value_device_resident": None if elapsed_dev is None else cd_per_step / (elapsed_dev / n_dev_steps),
+            "value_h2d_inclusive": cd_per_step / (sec_per_step + leg.h2d_s),
+            "transfer": {"out_bytes_per_gpu": leg.out_bytes, "h2d_input_ms": leg.h2d_s * 1e3,
                          "run_wall_ms": float(np.mean([s['wall_ms'] for s in step_stats])),
                          "d2h_tail_ms": float(np.mean([s['d2h_tail_ms'] for s in step_stats])),
                          "streamed_chunks": int(step_stats[-1]['streamed_chunks']),
-                         "d2h_gbs_over_run": None if host_out is None else out_bytes / (float(np.mean([s['wall_ms'] for s in step_stats])) * 1e-3) / 1e9,
+                         "d2h_gbs_over_run": None if host_out is None else leg.out_bytes / (float(np.mean([s['wall_ms'] for s in step_stats])) * 1e-3) / 1e9,
                          "stream_gbs_device_clock": [round(float(s_.get('stream_gbs', 0.0)), 2) for s_ in step_stats],
-                         "chunks_per_copy": [int(s_.get('copy_group', 0)) for s_ in step_stats],
-                         "pcie_spec_gbs": PCIE_SPEC_GBS, "host_numa_node": numa_node, "note": stream_note},
+                         "pcie_spec_gbs": PCIE_SPEC_GBS, "host_numa_node": b.numa_node},
             "occupancy": {"members_per_wave": lanes, "lanes_per_member": int(stats.get('lanes_per_member', 1) or 1),
                           "waves_per_gpu": waves, "simd_slots": 1024, "rounds": waves / 1024.0,
                           "note": "rounds < 1: the ensemble cannot fill the chip; the pass then takes as long as its slowest wave, "
                                   "i.e. one member's whole daily series (the latency floor, DESIGN.md section 4)" if waves < 1024 and S == 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "simplyp_%s_kernel<%d, false, %d>" % ("queue" if stats.get('queued') else "chain", opts.integrator,
-                                                                          int(stats.get('lanes_per_member', 1) or 1)),
+                         "kernel": leg.kernel_name(stats),
                          "kernel_ms": k_ms, "pilot_ms": stats.get('pilot_ms', 0.0),
                          "bytes_per_catchment_day": cfg['bytes_per_cd'], "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the path is fp64-VALU-bound, not HBM-bound: see fp64_valu"},
@@ -370,25 +486,145 @@ def main():
                           "frac_of_measured_issue": FLOPS_PER_ATTEMPT * (rhs / 6.0) / (k_ms * 1e-3) / 1e12 / FP64_FMA_MEASURED_TFLOPS,
                           "note": "useful lane-attempts only (lanes idling in a diverged wave are not counted); peak = all-FMA issue"
                                   + ("; flop count is the fp64 kernel's, this config runs fp32 stages" if args.config == 'c5' else "")},
+            "queue": {k: int(stats.get(k, 0)) for k in ('queue_waits', 'queue_longest_wait_polls', 'queue_longest_stall_polls')},
             "members_flagged": n_bad,
         }
         if not args.no_parity:
-            progress("parity sample against the CPU oracle")
-            line["parity"] = parity(args, eng, prob, opts, out, host_out, stats, e_local)
-        if not args.no_cpu_baseline and world == 1:
-            progress("cpu baseline")
-            line["cpu_baseline"] = cpu_baseline(prob, D, S)
+            b.progress("parity sample against the CPU oracle")
+            line["parity"] = parity(args, b.eng, leg.prob, opts, out, host_out, stats, e_local)
+
+    # ---- secondary legs: only beside the default workload (the driver's run); every rank takes part ----
+    secondary = {}
+    default_run = (args.config == 'c3' and args.members is None and args.rtol is None and args.chunk_days is None
+                   and args.lanes_per_member is None and not args.no_stream and not args.no_secondary)
+    if default_run:
+        secondary['c3_gof_only'] = leg_gof_only(b, leg)
+    prob_main = leg.prob
+    leg.free()
+    leg = out = host_out = None
+    if default_run:
+        secondary['c2'] = leg_secondary(b, 'c2')
+        secondary['c5'] = leg_secondary(b, 'c5')
+        vw = leg_value_weak(b, line, scaling)
+        if rank == 0:
+            line['value_weak'] = vw
+    if rank == 0:
+        if secondary:
+            line['secondary'] = secondary
+        if not args.no_cpu_baseline:
+            # on rank 0 at any world size (the other ranks wait at the barrier below), on all the cores this process may use
+            b.restore_affinity()
+            b.progress("cpu baseline")
+            line["cpu_baseline"] = cpu_baseline(prob_main, D, S)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def leg_secondary(b, config, steps=3):
+    """A BASELINE configuration beside the headline: every rank runs the config's single-GPU size (weak), `steps` timed passes
+    after one warm-up, table delivered to pinned host memory."""
+    import numpy as np
+    cfg = CONFIGS[config]
+    leg = Leg(b, config, 'weak', cfg['members'], stream=True, seed_base=0)
+    leg.one_step(leg.host_out)
+    elapsed, res, st = leg.timed(steps, leg.host_out, "secondary %s" % config)
+    k_ms = float(np.mean([s['kernel_ms'] for s in st]))
+    stats = res['stats']
+    d = None
+    if b.rank == 0:
+        d = {"workload": cfg['what'] % dict(rtol=leg.opts.rtol) + "; %d members per GPU; output: %s" % (leg.e_local, cfg['out']),
+             "value": leg.cd_per_step / (elapsed / steps), "unit": "catchment-days/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+             "table": "pinned host memory" if leg.host_out is not None else "left in HBM (%s)" % leg.stream_note,
+             "kernel": leg.kernel_name(stats), "kernel_ms": k_ms, "dtype": cfg['dtype'], "parity_grade": cfg['parity_grade'],
+             "roofline": {"bound": "hbm", "frac": leg.roofline_frac(k_ms), "bytes_per_catchment_day": cfg['bytes_per_cd']},
+             "rhs_evals_per_catchment_day": st[-1]['rhs_evals'] / leg.cd_rank, "simt_efficiency": stats.get('simt_efficiency'),
+             "lanes_per_member": int(stats.get('lanes_per_member', 1) or 1), "members_flagged": int((res['status'] != 0).sum().item())}
+        if config == 'c2':
+            d["replicas_bit_identical"] = bool((leg.out == leg.out[..., :1]).all().item())
+            if leg.host_out is not None:
+                rows = np.arange(0, leg.D, 97)
+                d["host_rows_equal"] = bool(b.torch.equal(b.torch.from_numpy(np.ascontiguousarray(leg.host_out[:, rows])).to(leg.out.device), leg.out[:, rows]))
+    leg.free()
+    return d
+
+
+def leg_gof_only(b, leg, steps=2):
+    """The consumer the big ensembles exist for (Development/2016/MCMC.ipynb cell 6, visualise_results.py:387-474): one
+    goodness-of-fit table per member.  The C3 pass with the daily table LEFT IN HBM, reduced there by simplyp_gof against the
+    shipped Tarland observations; only the statistics (8 x 6 values per member) go to the host -- the one mode PCIe does not cap."""
+    import numpy as np
+    from simplyp_amd import synthetic, visualise_results as vr
+    torch = b.torch
+    obs_dict = synthetic.tarland_observations()
+    obs = vr.observation_array(obs_dict, [1], leg.prob['met'].index)
+    f_tdp = float(synthetic.tarland_inputs()[5]['f_TDP'])
+    host_gof = None
+    rp = leg.dev[3]
+    if leg.scaling == 'strong' and b.world > 1:          # the device arrays hold the whole ensemble, the table this rank's block
+        from simplyp_amd import ensemble
+        lo, hi = ensemble.shard_bounds(leg.e_total, b.world, b.rank)
+        rp = rp[..., lo:hi].contiguous()
+
+    def one():
+        r = leg.one_step(None)
+        with torch.cuda.stream(b.stream):
+            gof, info = b.eng.gof(leg.out, leg.opts.out_mask, obs, f_tdp, rp,
+                                  member_of_slot=r['stats'].get('member_of_slot') if leg.opts.out_slot_order else None)
+            h = gof.cpu()
+        b.stream.synchronize()
+        return r, info, h
+
+    one()
+    b.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.progress("secondary c3 -> goodness of fit only")
+        r, info, host_gof = one()
+    b.fence()
+    dt = b.all_max(time.perf_counter() - t0)
+    if b.rank != 0:
+        return None
+    nse_q = host_gof[1, 0, 0].numpy()
+    return {"workload": "the headline C3 pass with the daily table left in HBM and reduced there to every member's goodness-of-fit "
+                        "table (simplyp_gof: N obs, NSE, log NSE, r2, bias, nRMSD + 2 likelihood sums x Q, SS, TDP, PP, TP, SRP "
+                        "against the shipped Tarland observations); only that table (%d B per member) goes to the host" % (8 * 6 * 8),
+            "value": leg.cd_per_step / (dt / steps), "unit": "catchment-days/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "kernel_ms": r['stats']['kernel_ms'], "gof_ms": info['kernel_ms'], "gof_bytes_read": int(info['bytes_read']),
+            "gof_hbm_frac": info['bytes_read'] / (info['kernel_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS if info['kernel_ms'] > 0 else None,
+            "best_member_nse_q": float(np.nanmax(nse_q)), "median_member_nse_q": float(np.nanmedian(nse_q))}
+
+
+def leg_value_weak(b, line, scaling, steps=2):
+    """The weak-scaling figure beside a strong headline: 100 000 members PER GPU (every rank its own draw: seed + rank), table
+    delivered to pinned host memory when every rank can page-lock its 43.8 GB, else left in HBM -- and labelled so."""
+    if b.world == 1:
+        return None if line is None else {"value": line['value'], "ms_per_step": line['ms_per_step'], "members_per_gpu": line['config']['members_per_gpu'],
+                                          "same_run_as_value": True, "note": "one GPU: the weak and the strong workload are the same run"}
+    if scaling != 'strong':
+        return None
+    leg = Leg(b, 'c3', 'weak', CONFIGS['c3']['members'], stream=True)
+    leg.one_step(leg.host_out)
+    elapsed, res, st = leg.timed(steps, leg.host_out, "value_weak: 100 000 members per GPU")
+    d = None
+    if b.rank == 0:
+        import numpy as np
+        d = {"value": leg.cd_per_step / (elapsed / steps), "unit": "catchment-days/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+             "members_per_gpu": leg.e_local, "members_total": leg.e_total, "scaling": "weak",
+             "table": "pinned host memory (same definition as `value`)" if leg.host_out is not None
+                      else "LEFT IN HBM -- %s; not comparable with `value`" % leg.stream_note,
+             "kernel_ms": float(np.mean([s['kernel_ms'] for s in st]))}
+    leg.free()
+    return d
+
+
 def parity(args, eng, prob, opts, out, host_out, stats, e_local):
-    """Accuracy that goes with the throughput number, two ways: (golden) the Tarland base member through the same
-    kernel and solver settings against the reference's own equations integrated by odeint(rtol=atol=1e-12)
-    (tests/golden, recorded from the unmodified reference); (timed_run_sample) seeded members pulled out of the
-    BENCHMARKED table -- slot-ordered, written by the timed kernel, host copy included -- against the CPU oracle."""
+    """Accuracy that goes with the throughput number, two ways: (golden) members through the same kernel and solver settings
+    against the reference's own equations integrated by odeint(rtol=atol=1e-12) (tests/golden, recorded from the unmodified
+    reference): the Tarland base member, the six members the step controller was tuned on and 16 members of a held-out draw;
+    (timed_run_sample) seeded members pulled out of the BENCHMARKED table -- slot-ordered, written by the timed kernel, host
+    copy included -- against the CPU oracle."""
     import numpy as np
     import torch
     res = {}
@@ -451,23 +687,43 @@ def cfg_parity_grade(args):
     return CONFIGS[args.config]['parity_grade']
 
 
+GOLDEN_REACH_COLS = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
+
+
 def parity_golden(eng, opts):
+    """The benchmarked kernel and solver settings against tables the UNMODIFIED reference produced with odeint at
+    rtol=atol=1e-12 (tests/golden/*.npz; generator: tests/golden/make_golden.py): the Tarland base member over 30 years, the six
+    members of the bench ensemble the knee-aware controller's constants were tuned on (30 years) and 16 members of a held-out
+    draw (3 years)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import helpers
     from simplyp_amd import marshal
     name = 'tarland_1981_2010_dynamic'
     m = helpers.marshal_scenario(name, E=64)
-    for k in ('integrator', 'substeps', 'rtol', 'atol', 'max_steps', 'project_vr'):
+    solver_keys = ('integrator', 'substeps', 'rtol', 'atol', 'max_steps', 'project_vr')
+    for k in solver_keys:
         setattr(m['opts'], k, getattr(opts, k))
     m['opts'].out_slot_order = 0
     out, status, _ = eng.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])
     got = out[..., 0].cpu().numpy()
     gold = helpers.golden_tables(name, 'tight')['R'][1]
-    cols = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
+    cols = GOLDEN_REACH_COLS
     rel = np.concatenate([np.abs(got[marshal.OUT_COLUMNS.index(c), :, 0] - gold[c].values) / np.abs(gold[c].values) for c in cols])
-    return {"max_rel_err": float(rel.max()), "p99_rel_err": float(np.percentile(rel, 99)), "bar": 1e-6,
-            "columns": "9 reach outputs x 10957 days", "against": "reference ode_f + driver, odeint rtol=atol=1e-12 (golden fixture)"}
+    res = {"max_rel_err": float(rel.max()), "p99_rel_err": float(np.percentile(rel, 99)), "bar": 1e-6,
+           "columns": "9 reach outputs x 10957 days", "against": "reference ode_f + driver, odeint rtol=atol=1e-12 (golden fixture)"}
+    for key, fname in (("knee_members", 'knee_members.npz'), ("heldout_members", 'heldout_members.npz')):
+        if not os.path.exists(os.path.join(helpers.GOLDEN, fname)):
+            continue
+        mm, tables = helpers.member_fixture_problem(fname, solver={k: getattr(opts, k) for k in solver_keys})
+        o2, st2, _ = eng.run(mm['forcing'], mm['doy'], mm['member_params'], mm['reach_params'], mm['up_ptr'], mm['up_idx'], mm['opts'])
+        g2 = o2.cpu().numpy()
+        worst = [max(helpers.max_rel_err(g2[marshal.OUT_COLUMNS.index(c), :, 0, k], tables[k][:, j], floor=1e-300) for j, c in enumerate(cols))
+                 for k in range(len(tables))]
+        res[key] = {"members": [int(x) for x in mm['members']], "worst_member_max_rel_err": float(max(worst)),
+                    "per_member": [float(x) for x in worst], "bar": 1e-6, "days": int(g2.shape[1]),
+                    "against": "the unmodified reference, odeint rtol=atol=1e-12, member by member (tests/golden/%s)" % fname}
+    return res
 
 
 def cpu_baseline(prob, D, S):
@@ -490,7 +746,11 @@ def cpu_baseline(prob, D, S):
                    out_reaches=prob['out_reaches'], n_threads=threads)
         return time.perf_counter() - t0
 
-    cores = min(os.cpu_count() or 1, 16)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    cores = min(usable, 16)
     per_member = 0.06 * S * D / 10957.0                     # ~core-seconds per member (measured for the 30-year single reach)
     n_all = max(cores, min(prob['member_params'].shape[1], int(30.0 / per_member)))
     n_one = max(1, min(prob['member_params'].shape[1], int(6.0 / per_member)))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 14
+#define SIMPLYP_ABI_VERSION 15
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -69,9 +69,15 @@ enum {
     SIMPLYP_OUT_QQ, SIMPLYP_OUT_QSA, SIMPLYP_OUT_QSS, SIMPLYP_OUT_QG, SIMPLYP_OUT_C_COVER_A,
     SIMPLYP_OUT_EPC0_A, SIMPLYP_OUT_EPC0_NC, SIMPLYP_OUT_TDPS_A, SIMPLYP_OUT_PLAB_A,
     SIMPLYP_OUT_CONC_TDPS_A, SIMPLYP_OUT_TDPS_NC, SIMPLYP_OUT_PLAB_NC, SIMPLYP_OUT_CONC_TDPS_NC,
+    SIMPLYP_N_OUT_REF,           /* = 25: the columns the reference's loop produces (model.py:644, :721-724)            */
+    /* 26th column, only with opts.snow = 1: the member's snow depth at the end of the day -- met_df['D_snow_end']
+     * (inputs.py:197-207), which the reference returns as df_TC['D_snow'] (model.py:775-776).  With the snow module run
+     * per member inside the kernel it is a per-member series; same arithmetic and order as the host function.           */
+    SIMPLYP_OUT_D_SNOW = SIMPLYP_N_OUT_REF,
     SIMPLYP_N_OUT
 };
-#define SIMPLYP_MASK_ALL    ((uint32_t)((1u << SIMPLYP_N_OUT) - 1u))
+#define SIMPLYP_MASK_ALL    ((uint32_t)((1u << SIMPLYP_N_OUT_REF) - 1u))   /* the reference's 25 columns                */
+#define SIMPLYP_MASK_D_SNOW ((uint32_t)(1u << SIMPLYP_OUT_D_SNOW))        /* accepted only together with opts.snow = 1 */
 /* the five documented model outputs of a reach (model.py:272-277): Vr, Qr, and the three
  * daily fluxes */
 #define SIMPLYP_MASK_REACH5 ((1u << SIMPLYP_OUT_VR) | (1u << SIMPLYP_OUT_QR) | (1u << SIMPLYP_OUT_MSUS_FLUX) | \
@@ -117,7 +123,7 @@ typedef struct {
     int32_t  dynamic_erod;   /* dynamic_options['Dynamic_erodibility'] == 'y' (model.py:555) */
     int32_t  run_mode_cal;   /* p_SU.run_mode == 'cal' -> Kf calibrated (model.py:449-453) */
     int32_t  sc_qr0;         /* zero-based reach that Qr0_init refers to (p['SC_Qr0']-1, model.py:386) */
-    uint32_t out_mask;       /* bit c set -> column c (SIMPLYP_OUT_*) is written           */
+    uint32_t out_mask;       /* bit c set -> column c (SIMPLYP_OUT_*) is written; SIMPLYP_MASK_D_SNOW needs opts.snow */
     double   step_len;       /* integration span per day, model.py:345 (default 1.0)       */
     int32_t  project_vr;     /* 1: at each day end reset Vr to the invariant of the reference's own equations,
                                 L_reach*Qr^(1-b_Q)/(a_Q*86400) (drift control; 0 = integrate Vr literally) */
@@ -183,10 +189,12 @@ typedef struct {
                                 byte reaching the host buffer (what the copy added to the run; 0 when not armed)   */
     double   wall_ms;        /* host wall clock from the entry of simplyp_run / simplyp_run_async to the end of simplyp_sync */
     double   stream_gbs;     /* simplyp_stream_out, chunked runs: table bytes / device time from the start of the main launch to
-                                the last output byte in the host buffer, GB/s (0 otherwise)                          */
-    int32_t  copy_group;     /* simplyp_stream_out, chunked runs: time chunks per device-to-host copy this run used: 1, or
-                                what the environment variable SIMPLYP_COPY_GROUP asked for (a diagnostic)               */
-    int32_t  reserved0;
+                                the last output byte in the host buffer, GB/s (0 otherwise) -- a diagnostic of the PCIe link */
+    uint64_t queue_waits;    /* task-queue kernel: dependency waits (own previous chunk, upstream reach, ring reader) that
+                                found their flag not yet raised and had to poll                                        */
+    uint64_t queue_longest_wait_polls;  /* the longest of them, in polls (~2 us each)                                   */
+    uint64_t queue_longest_stall_polls; /* the longest stretch of polls, inside any such wait, during which NO task of the run
+                                completed: what the wait's bound counts (simplyp_sync)                                 */
 } simplyp_stats;
 
 typedef struct simplyp_ctx simplyp_ctx;
@@ -267,10 +275,17 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
                       const int32_t* up_ptr, const int32_t* up_idx,
                       const int32_t* out_reaches, int32_t n_out_reaches,
                       double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals);
+/* simplyp_sync fails with SIMPLYP_ERR_DEVICE ("no task completed for ... polls") when a wave of the task-queue kernel waited
+ * for a dependency while NO task of the whole run completed for `max_polls` polls (2e7 x ~2 us; environment variable
+ * SIMPLYP_QUEUE_MAX_POLLS) -- a run that is merely slow (a shared GPU, a profiler) keeps completing tasks and never fails;
+ * results are incomplete after such an error.  On every exit, error or not, the streamed-output machinery is quiesced: the
+ * copier thread joined, both copy streams idle, nothing of the library still writes to the host buffer. */
 int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats);
 
 /*
  * simplyp_stream_out -- deliver the NEXT run's output table to host memory as well (one-shot; NULL disarms).
+ * One-shot means: the next simplyp_run / simplyp_run_async consumes the arm whatever its outcome -- also when it is refused
+ * for its arguments -- so a buffer the caller has since freed is never written by a later run.
  * The reference produces its 25 values per catchment-day in host memory (model.py:644, :721-724); an ensemble's table is
  * tens of GB, so the copy is overlapped with the computation: adaptive integrators then run through the time-chunk task
  * queue (opts.time_chunk_days = 0 then means 64-day chunks for a single reach, 256 for a network), the wave that finishes the

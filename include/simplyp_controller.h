@@ -1,0 +1,47 @@
+/*
+ * simplyp_controller.h -- the constants of the knee-aware step controller of integrator 2
+ * (SIMPLYP_INTEG_CASHKARP_AUG), in ONE place.
+ *
+ * Plain C macros, no code: included by the device kernels (simplyp_amd/csrc/simplyp_kernels.hip.h: SysAug::*, read by
+ * ck_day<SysAug> and ck_day_quad) and by the CPU oracle (oracle/simplyp_oracle.c: cashkarp_aug_day), so that the copies of
+ * the controller cannot drift apart.  Not part of the C ABI: nothing here is visible to a caller of libsimplyp_hip.so.
+ *
+ * What they steer: the reference's gate f_x (model.py:23-37) is a smooth step, C1 only -- its second
+ * derivative jumps at both ends ("knees") of its 1 %-wide zone.  Three gates sit in the right-hand side: soil box A and S at
+ * fc ... 1.01 fc (model.py:105, :109), groundwater at Qg_min ... 1.01 Qg_min (:121).  A 5(4) pair that steps across a knee
+ * drops to third order and its embedded estimate no longer bounds the error.
+ */
+#ifndef SIMPLYP_CONTROLLER_H
+#define SIMPLYP_CONTROLLER_H
+
+/* pb = Qr**b_Q, pk = Qr**k_M are only neutrally stable about their exact values and are not in the error norm: re-evaluate
+ * them after every RESYNC-th attempt of the day (a storm day can take 100+) */
+#define SIMPLYP_CTRL_RESYNC_EVERY 8
+/* error norm over the 7 physical states VsA VsS Vg Qr Msus TDPr PPr (the auxiliary states are functions of them, the four
+ * daily integrals quadratures of them) ... */
+#define SIMPLYP_CTRL_N_ERR 7
+/* ... plus Qr**k_M at AUX_WEIGHT x the tolerance (on a day when a nearly dry reach is wetted it grows 200-fold and its own
+ * truncation error showed in the sediment flux) */
+#define SIMPLYP_CTRL_AUX_WEIGHT 3.0
+/* A step that, along its first slope, has a knee within KINK_REACH x its length without having been aimed at it has its error
+ * estimate multiplied by KINK_SOIL (soil-water gates, crossed on most wet days) or KINK_GW (groundwater gate: zone 1 % of
+ * Qg_min wide, crossed a few times a year by members with a low Qg_min): it is accepted only if it is short. */
+#define SIMPLYP_CTRL_KINK_SOIL 10.0
+#define SIMPLYP_CTRL_KINK_GW 100.0
+#define SIMPLYP_CTRL_KINK_REACH 1.25
+/* Aim at the knee: a knee between KNEE_LO and KNEE_HI of the step (along the first slope) ends the step KNEE_OVER x that far,
+ * i.e. just past it; no inflation for such a step, except that one aimed at a groundwater knee keeps a factor KNEE_GW.
+ * Knees within the first KNEE_LO of a step are left alone. */
+#define SIMPLYP_CTRL_KNEE_LO 0.02
+#define SIMPLYP_CTRL_KNEE_HI 0.9
+#define SIMPLYP_CTRL_KNEE_OVER 1.05
+#define SIMPLYP_CTRL_KNEE_GW 10.0
+/* a day starts with this share of the step size carried over midnight (that size belongs to the smooth end of the previous
+ * day; the forcing jumps at midnight) */
+#define SIMPLYP_CTRL_DAY_START 0.2
+/* step-size rule shared by all adaptive schemes: h <- h * clamp(SAFETY * err^(-1/5), FAC_MIN, FAC_MAX) */
+#define SIMPLYP_CTRL_SAFETY 0.9
+#define SIMPLYP_CTRL_FAC_MIN 0.2
+#define SIMPLYP_CTRL_FAC_MAX 5.0
+
+#endif /* SIMPLYP_CONTROLLER_H */

@@ -17,8 +17,9 @@ HAS_F32_MIRROR = True      # integrator 3 (fp32 stages) has a same-arithmetic mi
 
 
 def build(force=False):
-    src = os.path.join(HERE, 'simplyp_oracle.c')
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    inc = os.path.join(os.path.dirname(HERE), 'include')
+    srcs = [os.path.join(HERE, 'simplyp_oracle.c'), os.path.join(inc, 'simplyp.h'), os.path.join(inc, 'simplyp_controller.h')]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(['make', '-C', HERE, '-B', 'libsimplyp_oracle.so'], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
@@ -73,6 +74,8 @@ def run(forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing
     _, S, E = rp.shape
     dims = abi.Dims(E, S, D, n_sets)
     ncols = bin(opts.out_mask).count('1')
+    if (opts.out_mask >> 25) & 1 and not opts.snow:
+        raise ValueError("column D_snow exists only with opts.snow = 1")
     if out_reaches is not None:
         out_reaches = np.ascontiguousarray(out_reaches, dtype=np.int32)
         n_or = len(out_reaches)

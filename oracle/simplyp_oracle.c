@@ -29,6 +29,7 @@
 #endif
 
 #include "../include/simplyp.h"
+#include "../include/simplyp_controller.h"    /* the step controller's constants, shared with the device kernels */
 
 /* ------------------------------------------------------------------------------------- */
 /* f_x, model.py:23-37.  threshold == 0 gives d == 0: the reference then divides 0/0 on the
@@ -231,9 +232,9 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
             st->rejected++;
         }
         double fac;
-        if (bad) fac = 0.2;
-        else if (err == 0.0) fac = 5.0;
-        else { fac = 0.9 * pow(err, -0.2); if (fac < 0.2) fac = 0.2; if (fac > 5.0) fac = 5.0; }
+        if (bad) fac = SIMPLYP_CTRL_FAC_MIN;
+        else if (err == 0.0) fac = SIMPLYP_CTRL_FAC_MAX;
+        else { fac = SIMPLYP_CTRL_SAFETY * pow(err, -0.2); if (fac < SIMPLYP_CTRL_FAC_MIN) fac = SIMPLYP_CTRL_FAC_MIN; if (fac > SIMPLYP_CTRL_FAC_MAX) fac = SIMPLYP_CTRL_FAC_MAX; }
         h = hh * fac;
     }
     *h_carry = h;
@@ -259,17 +260,18 @@ static void cashkarp_day(double* y, const ode_params* p, double T, double rtol, 
  * the Monte-Carlo members).  State vector z: VsA VsS Vg Qr Msus TDPr PPr EA ES pb pk | Qr_av Msus_out TDP_out PP_out.
  */
 #define NZ 15
-#define AUG_RESYNC 8
-#define AUG_NERR 7
-#define AUG_AUX_WEIGHT 3.0       /* SysAug::AUX_WEIGHT */
-#define AUG_KINK_SOIL 10.0       /* SysAug::KINK_SOIL: a step across a knee of a soil-water gate */
-#define AUG_KINK_REACH 1.25      /* SysAug::KINK_REACH: the end of the step is looked for this far along the first slope */
-#define AUG_KNEE_LO 0.02         /* SysAug::KNEE_LO, KNEE_HI, KNEE_OVER: a knee between 2 % and 90 % of the step, along the */
-#define AUG_KNEE_HI 0.9          /* first slope, ends the step 5 % past the knee (no inflation for such a step)            */
-#define AUG_KNEE_OVER 1.05
-#define AUG_DAY_START 0.2        /* SysAug::DAY_START: share of the carried step size a new day starts with */
-#define AUG_KNEE_GW 10.0          /* SysAug::KNEE_GW: a step aimed at a knee of the groundwater gate keeps this factor */
-#define AUG_KINK_GW 100.0        /* SysAug::KINK_GW: across a knee of the groundwater gate (zone 1 % of Qg_min wide) */
+/* the controller's constants: include/simplyp_controller.h, the same macros the kernels' SysAug::* are defined from */
+#define AUG_RESYNC SIMPLYP_CTRL_RESYNC_EVERY
+#define AUG_NERR SIMPLYP_CTRL_N_ERR
+#define AUG_AUX_WEIGHT SIMPLYP_CTRL_AUX_WEIGHT       /* SysAug::AUX_WEIGHT */
+#define AUG_KINK_SOIL SIMPLYP_CTRL_KINK_SOIL         /* SysAug::KINK_SOIL: a step across a knee of a soil-water gate */
+#define AUG_KINK_REACH SIMPLYP_CTRL_KINK_REACH       /* SysAug::KINK_REACH: the end of the step is looked for this far along the first slope */
+#define AUG_KNEE_LO SIMPLYP_CTRL_KNEE_LO             /* SysAug::KNEE_LO, KNEE_HI, KNEE_OVER: a knee between 2 % and 90 % of the step, along the */
+#define AUG_KNEE_HI SIMPLYP_CTRL_KNEE_HI             /* first slope, ends the step 5 % past the knee (no inflation for such a step)            */
+#define AUG_KNEE_OVER SIMPLYP_CTRL_KNEE_OVER
+#define AUG_DAY_START SIMPLYP_CTRL_DAY_START         /* SysAug::DAY_START: share of the carried step size a new day starts with */
+#define AUG_KNEE_GW SIMPLYP_CTRL_KNEE_GW             /* SysAug::KNEE_GW: a step aimed at a knee of the groundwater gate keeps this factor */
+#define AUG_KINK_GW SIMPLYP_CTRL_KINK_GW             /* SysAug::KINK_GW: across a knee of the groundwater gate (zone 1 % of Qg_min wide) */
 static void ode_aug(const double* z, const ode_params* p, double invKv, double* dz)
 {
     double VsA = z[0], VsS = z[1], Vg = z[2], Qr = z[3], Msus = z[4], TDPr = z[5], PPr = z[6];
@@ -415,9 +417,9 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
          * wavefront attempt in lockstep, so this test is wave-uniform there) */
         if (attempts % AUG_RESYNC == 0 && t < T) { z[9] = pow(z[3], p->b_Q); z[10] = pow(z[3], p->k_M); }
         double fac;
-        if (bad) fac = 0.2;
-        else if (err == 0.0) fac = 5.0;
-        else { fac = 0.9 * pow(err, -0.2); if (fac < 0.2) fac = 0.2; if (fac > 5.0) fac = 5.0; }
+        if (bad) fac = SIMPLYP_CTRL_FAC_MIN;
+        else if (err == 0.0) fac = SIMPLYP_CTRL_FAC_MAX;
+        else { fac = SIMPLYP_CTRL_SAFETY * pow(err, -0.2); if (fac < SIMPLYP_CTRL_FAC_MIN) fac = SIMPLYP_CTRL_FAC_MIN; if (fac > SIMPLYP_CTRL_FAC_MAX) fac = SIMPLYP_CTRL_FAC_MAX; }
         /* (a step that was cut to end at a knee and accepted does not shorten the step size carried on) */
         if (!(targeted && !bad && err <= 1.0 && hh * fac < h)) h = hh * fac;
     }
@@ -594,10 +596,10 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
             st->rejected++;
         }
         float fac;
-        if (bad) fac = 0.2f;
+        if (bad) fac = (float)SIMPLYP_CTRL_FAC_MIN;
         else {
-            fac = 0.9f * powf(err, -0.2f);               /* err == 0 -> +inf -> 5 */
-            fac = fminf(fmaxf(fac, 0.2f), 5.0f);
+            fac = (float)SIMPLYP_CTRL_SAFETY * powf(err, -0.2f);               /* err == 0 -> +inf -> 5 */
+            fac = fminf(fmaxf(fac, (float)SIMPLYP_CTRL_FAC_MIN), (float)SIMPLYP_CTRL_FAC_MAX);
         }
         h = hh * fac;
         if (attempts % AUG_RESYNC == 0 && t < T) {
@@ -829,6 +831,7 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
                 row[12] = Qq_i; row[13] = QsA0; row[14] = QsS0; row[15] = Qg0; row[16] = C_cover_A;   /* :721 */
                 row[17] = EPC0_A_i; row[18] = EPC0_NC_i; row[19] = TDPs0_A; row[20] = Plab0_A;
                 row[21] = conc_TDPs_A; row[22] = TDPs0_NC; row[23] = Plab0_NC; row[24] = conc_TDPs_NC; /* :722-723 */
+                row[SIMPLYP_OUT_D_SNOW] = D_snow;      /* met_df['D_snow_end'], inputs.py:200, :205 (written only with o->snow) */
                 for (int c = 0; c < SIMPLYP_N_OUT; ++c)
                     if (col_of[c] >= 0)
                         out[(((size_t)col_of[c] * D + idx) * n_out_reaches + slot) * E + e] = row[c];

@@ -2,7 +2,7 @@
 
 import ctypes as C
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1
@@ -34,8 +34,8 @@ class Stats(C.Structure):
     _fields_ = [('rhs_evals', C.c_uint64), ('steps', C.c_uint64), ('rejected', C.c_uint64),
                 ('kernel_ms', C.c_double), ('pilot_ms', C.c_double), ('simt_efficiency', C.c_double), ('n_launches', C.c_int32), ('balanced', C.c_int32),
                 ('queued', C.c_int32), ('lanes_per_wave', C.c_int32), ('lanes_per_member', C.c_int32), ('streamed_chunks', C.c_int32),
-                ('d2h_tail_ms', C.c_double), ('wall_ms', C.c_double), ('stream_gbs', C.c_double), ('copy_group', C.c_int32),
-                ('reserved0', C.c_int32)]
+                ('d2h_tail_ms', C.c_double), ('wall_ms', C.c_double), ('stream_gbs', C.c_double),
+                ('queue_waits', C.c_uint64), ('queue_longest_wait_polls', C.c_uint64), ('queue_longest_stall_polls', C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}

@@ -39,7 +39,7 @@ struct simplyp_ctx {
     hipEvent_t ev_start = nullptr, ev_main = nullptr, ev_stop = nullptr;
     DeviceBuf route;          // [n_slots][4][D][E] fp64
     DeviceBuf sched;          // int32 schedule arrays
-    DeviceBuf counters;       // 4 x uint64
+    DeviceBuf counters;       // N_COUNTERS x uint64: rhs, steps, rejected, wave-level attempts, queue waits / longest wait / longest stall
     DeviceBuf balance;        // [E] uint32 pilot counts + [E] int32 permutation
     DeviceBuf sorted_params;  // slot-ordered copies of member_params, reach_params, forcing_of_member
     DeviceBuf gof_lists;      // goodness-of-fit day lists, observations, shifts (simplyp_gof)
@@ -47,15 +47,12 @@ struct simplyp_ctx {
     DeviceBuf queue;          // ticket, error, done[n_groups] (uint32) | ckpt[CKPT_N][E] (double)
     // streamed output (simplyp_stream_out): the armed destination, the chunk flags the queue kernel raises in pinned host
     // memory, and the host thread that turns a raised flag into the D2H copies of that chunk's rows on `copy_stream`
+    static constexpr int N_COUNTERS = 8;
     static constexpr int N_COPY_STREAMS = 2;            // measured on C3: 1 stream 803 ms per pass, 2: 795, 3: 796, 4: 799
     hipStream_t copy_stream = nullptr;                  // = copy_streams[0]: carries ev_copy_done
     hipStream_t copy_streams[N_COPY_STREAMS] = {};      // the chunk copies take these in turn
     hipEvent_t ev_copy_done = nullptr, ev_copy_join[N_COPY_STREAMS] = {};
     int n_copy_streams = 2;
-    // Time chunks per copy: 1 = every finished chunk travels at once (one copy per column, 51 MB for C3); SIMPLYP_COPY_GROUP = n
-    // sends n chunks per copy (a diagnostic: on this pool a streamed pass sometimes runs at 45-50 instead of 56 GB/s for a
-    // minute or so, on the same box with the same settings -- larger copies do not cure it: profiles/r02_experiments.md)
-    int copy_group = 1;
     double* stream_host = nullptr;      // armed for the next run (one-shot)
     int64_t stream_host_bytes = 0;
     uint32_t* host_ready = nullptr;     // [host_ready_cap] hipHostMalloc
@@ -64,8 +61,7 @@ struct simplyp_ctx {
     struct CopyPlan {
         const double* dev = nullptr;
         double* host = nullptr;
-        int ncols = 0, n_chunks = 0, chunk_days = 0, group = 1;
-        bool group_forced = false;      // this run's group came from SIMPLYP_COPY_GROUP: the context does not learn from it
+        int ncols = 0, n_chunks = 0, chunk_days = 0;
         size_t D = 0, row_doubles = 0;  // rows per column, doubles per row (n_out_reaches * E)
     } copy_plan;
     std::thread copier;
@@ -359,9 +355,10 @@ void copier_main(simplyp_ctx* ctx)
     bool run_over = false;
     unsigned n_issued = 0;
     const bool dbg = getenv("SIMPLYP_DEBUG") != nullptr;
-    const int group = std::max(1, p.group);
-    for (int c0 = 0; c0 < p.n_chunks; c0 += group) {
-        const int c1 = std::min(p.n_chunks, c0 + group);       // chunks [c0, c1) travel as one copy per column
+    // every finished chunk travels at once: one copy per column (51 MB for C3).  Several chunks per copy were tried against the
+    // spells at 45-50 instead of 56 GB/s this pool sometimes has, and changed nothing (profiles/r02_experiments.md)
+    for (int c0 = 0; c0 < p.n_chunks; ++c0) {
+        const int c1 = c0 + 1;
         for (int c = c0; c < c1; ++c) {
             while (!run_over && __atomic_load_n(&ctx->host_ready[c], __ATOMIC_ACQUIRE) == 0u) {
                 if (ctx->run_over.load(std::memory_order_acquire)) { run_over = true; break; }
@@ -418,8 +415,10 @@ int check_args(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* o
         return fail(ctx, SIMPLYP_ERR_ARG, "lanes_per_member = 4 exists for integrator 2 (Cash-Karp on the augmented system) only");
     if (!(opts->step_len > 0.0)) return fail(ctx, SIMPLYP_ERR_ARG, "step_len must be > 0");
     if (opts->sc_qr0 < 0 || opts->sc_qr0 >= dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "sc_qr0 out of range");
-    if ((opts->out_mask & SIMPLYP_MASK_ALL) == 0u || (opts->out_mask & ~SIMPLYP_MASK_ALL) != 0u)
+    if (opts->out_mask == 0u || (opts->out_mask & ~(SIMPLYP_MASK_ALL | SIMPLYP_MASK_D_SNOW)) != 0u)
         return fail(ctx, SIMPLYP_ERR_ARG, "out_mask must select 1..%d of the columns", (int)SIMPLYP_N_OUT);
+    if ((opts->out_mask & SIMPLYP_MASK_D_SNOW) != 0u && !opts->snow)
+        return fail(ctx, SIMPLYP_ERR_ARG, "column D_snow (SIMPLYP_OUT_D_SNOW) exists only when the snow module runs in the kernel (opts.snow = 1)");
     if (out_reaches) {
         if (n_out_reaches <= 0 || n_out_reaches > dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "bad n_out_reaches");
         for (int k = 0; k < n_out_reaches; ++k)
@@ -533,7 +532,7 @@ int64_t simplyp_out_bytes(const simplyp_dims* dims, const simplyp_opts* opts, in
     if (!dims || !opts) return 0;
     const int64_t nor = n_out_reaches > 0 ? n_out_reaches : dims->S;
     const int64_t rows = opts->n_periods > 0 ? opts->n_periods : dims->D;
-    return (int64_t)popcount32(opts->out_mask & SIMPLYP_MASK_ALL) * rows * nor * dims->E * (int64_t)sizeof(double);
+    return (int64_t)popcount32(opts->out_mask & (SIMPLYP_MASK_ALL | SIMPLYP_MASK_D_SNOW)) * rows * nor * dims->E * (int64_t)sizeof(double);
 }
 
 static int plan_impl(int32_t S, const int32_t* up_ptr, const int32_t* up_idx, int32_t* n_launches, int32_t* n_slots,
@@ -584,17 +583,19 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
                           const int32_t* out_reaches, int32_t n_out_reaches,
                           double* out, int32_t* member_status, int32_t* member_of_slot, uint32_t* member_rhs_evals)
 {
-    int rc = check_args(ctx, dims, opts, forcing, member_params, reach_params, up_ptr, out, member_status,
-                        out_reaches, n_out_reaches);
-    if (rc != SIMPLYP_OK) return rc;
+    if (!ctx) return SIMPLYP_ERR_ARG;
     if (ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "a run is already pending on this context; call simplyp_sync");
-    ctx->t_begin = std::chrono::steady_clock::now();
-    // streamed output armed by simplyp_stream_out: one-shot
+    // streamed output armed by simplyp_stream_out: one-shot, consumed by THIS call whatever becomes of it -- a run refused for
+    // its arguments must not leave the arm behind for a later run to fire into a buffer the caller has dropped since
     double* const host_out = ctx->stream_host;
     const int64_t host_out_bytes = ctx->stream_host_bytes;
     ctx->stream_host = nullptr; ctx->stream_host_bytes = 0;
+    int rc = check_args(ctx, dims, opts, forcing, member_params, reach_params, up_ptr, out, member_status,
+                        out_reaches, n_out_reaches);
+    if (rc != SIMPLYP_OK) return rc;
+    ctx->t_begin = std::chrono::steady_clock::now();
     ctx->copy_pending = false; ctx->copy_error = 0; ctx->streamed_chunks = 0;
-    ctx->copy_plan.n_chunks = 0; ctx->copy_plan.group = 1; ctx->copy_plan.group_forced = false;
+    ctx->copy_plan.n_chunks = 0;
     if (host_out && host_out_bytes < simplyp_out_bytes(dims, opts, out_reaches ? n_out_reaches : dims->S))
         return fail(ctx, SIMPLYP_ERR_ARG, "simplyp_stream_out: host buffer of %lld bytes is smaller than the output table (%lld)",
                     (long long)host_out_bytes, (long long)simplyp_out_bytes(dims, opts, out_reaches ? n_out_reaches : dims->S));
@@ -614,7 +615,7 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
 
     // ---- device scratch: schedule, counters (the routing series are sized where their length is known: pilot windows,
     // ring buffers of the task queue, or whole-run series of the chain kernel) ----
-    rc = ensure(ctx, ctx->counters, 4 * sizeof(unsigned long long));
+    rc = ensure(ctx, ctx->counters, simplyp_ctx::N_COUNTERS * sizeof(unsigned long long));
     if (rc != SIMPLYP_OK) return rc;
 
     // int32 schedule block: up_ptr | up_idx | route_slot | out_slot | per launch: chain_ptr | chain_reach
@@ -658,7 +659,7 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     // pageable source: the copy is staged before hipMemcpyAsync returns, `host` may go out of scope
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sched.ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, simplyp_ctx::N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(member_status, 0, (size_t)E * sizeof(int32_t), ctx->stream));
     if (member_rhs_evals) HIP_TRY(ctx, hipMemsetAsync(member_rhs_evals, 0, (size_t)E * sizeof(uint32_t), ctx->stream));
 
@@ -674,7 +675,7 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     a.up_ptr = dsched + off_up_ptr; a.up_idx = dsched + off_up_idx;
     a.route_slot = dsched + off_rslot; a.out_slot = dsched + off_oslot;
     a.n_out_reaches = n_out_reaches;
-    a.out_mask = opts->out_mask & SIMPLYP_MASK_ALL;
+    a.out_mask = opts->out_mask & (SIMPLYP_MASK_ALL | SIMPLYP_MASK_D_SNOW);
     a.integrator = opts->integrator; a.substeps = opts->substeps; a.max_steps = opts->max_steps;
     a.dynamic_epc0 = opts->dynamic_epc0; a.dynamic_erod = opts->dynamic_erod;
     a.run_mode_cal = opts->run_mode_cal; a.sc_qr0 = opts->sc_qr0; a.project_vr = opts->project_vr;
@@ -817,7 +818,7 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
         HIP_TRY(ctx, hipMemcpyAsync(d_perm, perm.data(), (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // the pilot's bookkeeping must not leak into the real run
-        HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 4 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, simplyp_ctx::N_COUNTERS * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(member_status, 0, (size_t)E * sizeof(int32_t), ctx->stream));
         a.perm = d_perm;
         ctx->balanced = 1;
@@ -890,7 +891,7 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
             const size_t off_dptr = qi.size(); qi.insert(qi.end(), down_ptr.begin(), down_ptr.end());
             const size_t off_didx = qi.size(); qi.insert(qi.end(), down_idx.begin(), down_idx.end());
             const size_t off_qslot = qi.size(); qi.insert(qi.end(), qslot.begin(), qslot.end());
-            const size_t flags_bytes = (((size_t)S * G + 2) * sizeof(unsigned) + 255) / 256 * 256;
+            const size_t flags_bytes = (((size_t)S * G + 4) * sizeof(unsigned) + 255) / 256 * 256;      // ticket, error, progress, (pad), done[S][G]
             const size_t ints_bytes = (qi.size() * sizeof(int) + 255) / 256 * 256;
             rc = ensure(ctx, ctx->queue, flags_bytes + ints_bytes + (size_t)S * simplyp::CKPT_N * E * sizeof(double));
             if (rc != SIMPLYP_OK) return rc;
@@ -902,7 +903,7 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
             simplyp::QueueArgs q;
             unsigned* flags = (unsigned*)base;
             const int* dq = (const int*)(base + flags_bytes);
-            q.ticket = flags; q.error = flags + 1; q.done = flags + 2;
+            q.ticket = flags; q.error = flags + 1; q.progress = flags + 2; q.done = flags + 4;
             q.task_reach = dq; q.task_chunk = dq + pair_idx.size();
             q.down_ptr = dq + off_dptr; q.down_idx = dq + off_didx;
             q.ckpt = (double*)(base + flags_bytes + ints_bytes);
@@ -925,14 +926,8 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
                 q.host_ready = ctx->host_ready;
                 ctx->copy_plan.n_chunks = n_chunks;
                 ctx->copy_plan.chunk_days = chunk_days;
-                ctx->copy_plan.group = ctx->copy_group;
-                ctx->copy_plan.group_forced = false;
-                if (const char* g_env = getenv("SIMPLYP_COPY_GROUP")) {
-                    ctx->copy_plan.group = std::max(1, std::min(64, atoi(g_env)));
-                    ctx->copy_plan.group_forced = true;
-                }
             }
-            q.max_polls = 20000000u;      // x (s_sleep 64 ~ 2 us): a wait longer than ~40 s means something is broken
+            q.max_polls = 20000000u;      // x (s_sleep 64 ~ 2 us): ~40 s in which NO task of the run completed means something is broken
             if (const char* mp_env = getenv("SIMPLYP_QUEUE_MAX_POLLS")) q.max_polls = (unsigned)strtoul(mp_env, nullptr, 10);
             simplyp::KernelArgs k = a;
             k.route = (double*)ctx->route.ptr;
@@ -991,6 +986,18 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     return SIMPLYP_OK;
 }
 
+// Whatever way simplyp_sync (or a failed launch) leaves: the copier thread is told the run is over and joined, both copy streams
+// are idle, nothing of the library still writes to the caller's host buffer, and the context can start another streamed run
+// (std::thread::operator= on a joinable thread would call std::terminate).
+static void quiesce_streaming(simplyp_ctx* ctx)
+{
+    ctx->run_over.store(1, std::memory_order_release);     // whatever chunk flag is still down stays down
+    if (ctx->copier.joinable()) ctx->copier.join();        // every chunk's copy is enqueued when it returns
+    for (int i = 0; i < simplyp_ctx::N_COPY_STREAMS; ++i)
+        if (ctx->copy_streams[i]) (void)hipStreamSynchronize(ctx->copy_streams[i]);
+    ctx->copy_pending = false;
+}
+
 // Errors met after work has been enqueued must not leave it in flight behind the caller's back.
 static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* opts,
                           const double* forcing, const int32_t* doy, const int32_t* period_of_day,
@@ -1004,9 +1011,7 @@ static int run_async_impl(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
                                   up_ptr, up_idx, out_reaches, n_out_reaches, out, member_status, member_of_slot, member_rhs_evals);
     if (rc != SIMPLYP_OK && ctx && !ctx->pending) {
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-        ctx->run_over.store(1, std::memory_order_release);
-        if (ctx->copier.joinable()) ctx->copier.join();
-        ctx->copy_pending = false;
+        quiesce_streaming(ctx);
     }
     return rc;
 }
@@ -1024,11 +1029,8 @@ int simplyp_run_async(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_
                                       member_rhs_evals))
 }
 
-int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
+static int sync_impl(simplyp_ctx* ctx, simplyp_stats* stats)
 {
-    if (!ctx) return SIMPLYP_ERR_ARG;
-    if (!ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "no run pending");
-    ctx->pending = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] sync: waiting for the stop event\n");
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
@@ -1036,10 +1038,8 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
     if (getenv("SIMPLYP_DEBUG")) fprintf(stderr, "[simplyp] sync: stream idle\n");
     float ms_tail = 0.f;
     double stream_gbs = 0.0;
-    int used_group = 0;
     const bool copied = ctx->copy_pending;
-    if (ctx->copy_pending) {
-        ctx->copy_pending = false;
+    if (copied) {
         ctx->run_over.store(1, std::memory_order_release);     // the launches are done: whatever flag is still down stays down
         if (ctx->copier.joinable()) ctx->copier.join();        // every chunk's copy is enqueued when it returns
         if (ctx->copy_error)
@@ -1053,17 +1053,18 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
             const simplyp_ctx::CopyPlan& cp = ctx->copy_plan;
             const double bytes = (double)cp.ncols * (double)cp.D * (double)cp.row_doubles * sizeof(double);
             stream_gbs = ms_run > 0.f ? bytes / (ms_run * 1e-3) / 1e9 : 0.0;
-            used_group = cp.group;
         }
     }
+    unsigned long long c[simplyp_ctx::N_COUNTERS] = {};
+    HIP_TRY(ctx, hipMemcpy(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
     if (ctx->queued) {
         unsigned err = 0;
         HIP_TRY(ctx, hipMemcpy(&err, (unsigned*)ctx->queue.ptr + 1, sizeof(err), hipMemcpyDeviceToHost));
-        if (err) return fail(ctx, SIMPLYP_ERR_DEVICE, "task-queue kernel: a wave timed out waiting for a time chunk; results are incomplete");
+        if (err)
+            return fail(ctx, SIMPLYP_ERR_DEVICE, "task-queue kernel: a wave waited for a time chunk while no task of the run completed for "
+                        "%llu polls (bound: SIMPLYP_QUEUE_MAX_POLLS); results are incomplete", c[6]);
     }
     if (stats) {
-        unsigned long long c[4] = {0, 0, 0, 0};
-        HIP_TRY(ctx, hipMemcpy(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
         float ms = 0.f, ms_pilot = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_main, ctx->ev_stop));
         HIP_TRY(ctx, hipEventElapsedTime(&ms_pilot, ctx->ev_start, ctx->ev_main));
@@ -1071,7 +1072,7 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->rhs_evals = c[0]; stats->steps = c[1]; stats->rejected = c[2];
         stats->kernel_ms = ms;
         // lanes doing useful work per issued attempt: (attempts summed over lanes) / (64 x wave-level attempts)
-        // (of all 64 lanes, also when a wave carries fewer members; a member spread over a quad occupies four)
+        // (of all 64 lanes, also when a wave carries fewer members; a member spread over several lanes occupies them all)
         stats->simt_efficiency = c[3] ? (double)(c[0] / 6) * ctx->team / (64.0 * (double)c[3]) : 1.0;
         stats->pilot_ms = ctx->balanced ? ms_pilot : 0.0;
         stats->n_launches = ctx->n_launches;
@@ -1082,10 +1083,27 @@ int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->streamed_chunks = copied ? ctx->streamed_chunks : 0;
         stats->d2h_tail_ms = copied ? ms_tail : 0.0;
         stats->stream_gbs = stream_gbs;
-        stats->copy_group = used_group;
+        stats->queue_waits = ctx->queued ? c[4] : 0;
+        stats->queue_longest_wait_polls = ctx->queued ? c[5] : 0;
+        stats->queue_longest_stall_polls = ctx->queued ? c[6] : 0;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();
     }
     return SIMPLYP_OK;
+}
+
+int simplyp_sync(simplyp_ctx* ctx, simplyp_stats* stats)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (!ctx->pending) return fail(ctx, SIMPLYP_ERR_ARG, "no run pending");
+    ctx->pending = false;
+    int rc;
+    try {
+        rc = sync_impl(ctx, stats);
+    } catch (const std::exception& e) {
+        rc = fail(ctx, SIMPLYP_ERR_DEVICE, "unexpected host error: %s", e.what());
+    }
+    quiesce_streaming(ctx);      // on every exit, error or not (a second join / synchronize is a no-op)
+    return rc;
 }
 
 int simplyp_stream_out(simplyp_ctx* ctx, double* host_out, int64_t host_bytes)

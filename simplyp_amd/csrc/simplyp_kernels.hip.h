@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/simplyp.h"
+#include "../../include/simplyp_controller.h"     // the step controller's constants, shared with the CPU oracle
 
 namespace simplyp {
 
@@ -47,7 +48,7 @@ struct KernelArgs {
     double* out;                    // [ncols][D][n_out_reaches][E]
     int* status;                    // [E]
     unsigned* member_rhs;           // [E] or nullptr: rhs evaluations per member
-    unsigned long long* counters;   // rhs, steps, rejected, wave-level attempts
+    unsigned long long* counters;   // rhs, steps, rejected, wave-level attempts | queue: waits, longest wait, longest stall (polls)
     double* route;                  // [n_slots][4][route_days][E] daily series handed downstream
     int route_days;                 // rows per series buffer: D (chain kernel) or a ring of a few time chunks (queue)
     const int* chain_ptr;           // [n_chains+1]   (this launch; chain kernel)
@@ -341,10 +342,10 @@ struct SysAug {
     // pb, pk are only neutrally stable about Qr**b_Q, Qr**k_M and are not in the error norm: re-evaluate them after every
     // 8th attempt of the day (a storm day can take 100+), as the oracle does.  With every 16 accepted steps, 3 of 8192
     // Monte-Carlo members had a day above 1e-6 in the sediment / PP fluxes (tools/probe_tolerance.py).
-    static constexpr int RESYNC_EVERY = 8;
+    static constexpr int RESYNC_EVERY = SIMPLYP_CTRL_RESYNC_EVERY;
     // error norm over the 7 physical states (the auxiliary states are functions of them, the daily integrals
     // quadratures of them; see oracle/simplyp_oracle.c)
-    static constexpr int N_ERR = 7;
+    static constexpr int N_ERR = SIMPLYP_CTRL_N_ERR;
     static constexpr bool QUAD_IN_NORM = false;
     // Error scale of the two soil boxes: rtol * max(|Vs - fc|, 0.01 fc) instead of rtol * |Vs|.  Everything downstream sees a
     // soil box through Vs - fc (the gate argument and the flow (Vs - fc)/T_s, model.py:105-110), a difference of ~1 mm between
@@ -366,8 +367,8 @@ struct SysAug {
     // zone is 1 % of Qg_min wide and is crossed a few times a year by members with a low Qg_min: with 10 there, 7 members of
     // the 100 000 still had a day at 5-9e-7)
     static constexpr bool KINK_AWARE = true;
-    static constexpr double KINK_SOIL = 10.0, KINK_GW = 100.0;
-    static constexpr double KINK_REACH = 1.25;
+    static constexpr double KINK_SOIL = SIMPLYP_CTRL_KINK_SOIL, KINK_GW = SIMPLYP_CTRL_KINK_GW;      // (values: include/simplyp_controller.h)
+    static constexpr double KINK_REACH = SIMPLYP_CTRL_KINK_REACH;
     // Better than paying for a crossing with a rejected attempt: aim at the knee.  After the first stage the time to the
     // nearest knee along the first slope is known; if it lies inside the step (between KNEE_LO and KNEE_HI of it) the step is
     // cut to end KNEE_OVER x that far, i.e. just past the knee -- the right-hand side is then smooth over all but the last
@@ -378,9 +379,10 @@ struct SysAug {
     // DAY_START: a day starts with this share of the step size carried over midnight (see ck_day).
     // (A step aimed at a knee of the groundwater gate keeps a factor KNEE_GW: where the first slope misjudges the crossing
     // time the knee sits well inside the step, and that gate does not forgive it -- one member-day of the 100 000 at 1.5e-6.)
-    static constexpr double KNEE_LO = 0.02, KNEE_HI = 0.9, KNEE_OVER = 1.05, KNEE_GW = 10.0;
-    static constexpr double DAY_START = 0.2;
-    static constexpr double AUX_WEIGHT = 3.0;
+    static constexpr double KNEE_LO = SIMPLYP_CTRL_KNEE_LO, KNEE_HI = SIMPLYP_CTRL_KNEE_HI, KNEE_OVER = SIMPLYP_CTRL_KNEE_OVER,
+                            KNEE_GW = SIMPLYP_CTRL_KNEE_GW;
+    static constexpr double DAY_START = SIMPLYP_CTRL_DAY_START;
+    static constexpr double AUX_WEIGHT = SIMPLYP_CTRL_AUX_WEIGHT;
     // z[9] carries cQ * Qr**b_Q (the factor the flow equation multiplies it with, folded into the state: one multiplication
     // less per right-hand side; its ODE is linear in it, so the scaling changes nothing else)
     static __device__ __forceinline__ void resync(double (&z)[11], const DayConst& c)
@@ -454,8 +456,8 @@ struct SysAugF {
     typedef float real;
     typedef DayConstF dayconst;
     static constexpr int NS = 11;
-    static constexpr int RESYNC_EVERY = 8;
-    static constexpr int N_ERR = 7;
+    static constexpr int RESYNC_EVERY = SIMPLYP_CTRL_RESYNC_EVERY;
+    static constexpr int N_ERR = SIMPLYP_CTRL_N_ERR;
     static constexpr bool QUAD_IN_NORM = false;
     // The plain controller (relative tolerance on every state, no knee logic): at this mode's tolerances (rtol ~ 1e-5) the
     // float stages, not the knees, limit the accuracy -- rtol * |Vs - fc| would be one float ulp of a 300 mm store -- and the
@@ -699,8 +701,8 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         // err == inf gives 0 -> 0.2 (err is never NaN: v_max_f64 drops NaNs).
         // (raw v_log_f32 / v_exp_f32: the library versions add denormal-range fix-ups, ~12 instructions, for arguments
         // whose factor is clamped to 5 anyway)
-        float fac = 0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
-        fac = fminf(fmaxf(fac, 0.2f), 5.0f);
+        float fac = (float)SIMPLYP_CTRL_SAFETY * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
+        fac = fminf(fmaxf(fac, (float)SIMPLYP_CTRL_FAC_MIN), (float)SIMPLYP_CTRL_FAC_MAX);
         const bool accept = alive && !bad && (err <= (R)1 || last_chance);
         bool give_up = false;
         n_alive += alive ? 1u : 0u;
@@ -715,7 +717,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         const bool any_bad = __any(alive && bad);
         if (any_bad) {
             give_up = alive && bad && (last_chance || hh <= (R)1.0e-9 * T);
-            if (alive && bad) fac = 0.2f;
+            if (alive && bad) fac = (float)SIMPLYP_CTRL_FAC_MIN;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 k1[i] = bad ? (R)0 : k1[i]; k3[i] = bad ? (R)0 : k3[i]; k4[i] = bad ? (R)0 : k4[i]; k6[i] = bad ? (R)0 : k6[i];
@@ -1052,8 +1054,8 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         const bool bad = !(err < huge);
 
         ++trip;
-        float fac = 0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
-        fac = fminf(fmaxf(fac, 0.2f), 5.0f);
+        float fac = (float)SIMPLYP_CTRL_SAFETY * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
+        fac = fminf(fmaxf(fac, (float)SIMPLYP_CTRL_FAC_MIN), (float)SIMPLYP_CTRL_FAC_MAX);
         const bool accept = alive && !bad && (err <= (R)1 || last_chance);
         bool give_up = false;
         n_alive += alive ? 1u : 0u;
@@ -1063,7 +1065,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
         const bool any_bad = __any(alive && bad);
         if (any_bad) {
             give_up = alive && bad && (last_chance || hh <= (R)1.0e-9 * T);
-            if (alive && bad) fac = 0.2f;
+            if (alive && bad) fac = (float)SIMPLYP_CTRL_FAC_MIN;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 k1[i] = bad ? (R)0 : k1[i]; k3[i] = bad ? (R)0 : k3[i]; k4[i] = bad ? (R)0 : k4[i]; k6[i] = bad ? (R)0 : k6[i];
@@ -1466,6 +1468,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                         PUT(SIMPLYP_OUT_C_COVER_A, C_cover_A) PUT(SIMPLYP_OUT_EPC0_A, EPC0_A) PUT(SIMPLYP_OUT_EPC0_NC, EPC0_NC)
                         PUT(SIMPLYP_OUT_TDPS_A, TDPs_A) PUT(SIMPLYP_OUT_PLAB_A, Plab_A) PUT(SIMPLYP_OUT_CONC_TDPS_A, conc_A)
                         PUT(SIMPLYP_OUT_TDPS_NC, TDPs_NC) PUT(SIMPLYP_OUT_PLAB_NC, Plab_NC) PUT(SIMPLYP_OUT_CONC_TDPS_NC, conc_NC)
+                        if (SNOW) { PUT(SIMPLYP_OUT_D_SNOW, D_snow) }      // met_df['D_snow_end'] (inputs.py:200, :205) -> df_TC['D_snow'] (model.py:775-776)
 #undef PUT
                     }
                 }
@@ -1547,11 +1550,13 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs
 // Hand-off (MI355X_MICROARCH.md, "Valid forms"): producer = plain stores, s_waitcnt vmcnt(0), agent-scope
 // release, s_waitcnt vmcnt(0) (asm, so the compiler cannot drop it), relaxed agent-scope flag store;
 // consumer = relaxed agent-scope polls (wave-uniform address, with s_sleep), agent-scope acquire, s_waitcnt vmcnt(0),
-// then plain loads.  The spin is bounded: on timeout the wave raises q.error and every worker drains.
+// then plain loads.  The spin is bounded (by lack of progress of the whole run, queue_wait): the wave then raises q.error and
+// every worker drains.
 struct QueueArgs {
     unsigned* ticket;          // next task number
     unsigned* done;            // [S][n_groups] chunks completed per (reach, member group)
     unsigned* error;           // set to 1 on a wait timeout
+    unsigned* progress;        // tasks completed so far, by anybody: what a waiting wave watches (queue_wait)
     double* ckpt;              // [S][CKPT_N][E]
     const int* task_reach;     // [n_pairs] reach of the (reach, chunk) pair, in dependency order
     const int* task_chunk;     // [n_pairs]
@@ -1570,18 +1575,37 @@ struct QueueArgs {
 // Wait until *flag >= need.  Executed by the whole wave on a wave-uniform address (the 64 identical loads are
 // one request) and made scalar with readfirstlane, so the spin is a scalar loop: no lane-masked control flow
 // around it.
-__device__ __forceinline__ bool queue_wait(const QueueArgs& q, const unsigned* flag, unsigned need)
+// The bound is on PROGRESS, not on time: the wait fails only when no task of the whole run has completed for q.max_polls
+// polls in a row (`q.progress` is bumped by every finished task).  A run that is merely slow -- a GPU shared with another
+// process, a profiler that turns the streamed copies into shader blits -- keeps completing tasks and never trips it; a
+// dependency that can no longer be satisfied (the deadlock the ticket order rules out, a worker lost to a fault) does, after
+// max_polls x ~2 us.  (Until round 3 the bound was the wait's own poll count: any healthy run slowed down enough would have
+// failed with "timed out".)
+struct QueueWaitStats { unsigned waits, longest_wait, longest_stall; };
+
+__device__ __forceinline__ unsigned queue_load(const unsigned* p)
 {
-    unsigned polls = 0;
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ bool queue_wait(const QueueArgs& q, const unsigned* flag, unsigned need, QueueWaitStats& ws)
+{
+    if (queue_load(flag) >= need) return true;
+    ++ws.waits;
+    unsigned polls = 0, stall = 0, seen = queue_load(q.progress);
+    bool ok;
     for (;;) {
-        const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane(
-            (int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (v >= need) return true;
         __builtin_amdgcn_s_sleep(64);
-        const unsigned err = (unsigned)__builtin_amdgcn_readfirstlane(
-            (int)__hip_atomic_load(q.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (++polls > q.max_polls || err != 0u) return false;
+        ++polls;
+        if (queue_load(flag) >= need) { ok = true; break; }
+        const unsigned now = queue_load(q.progress);
+        stall = (now != seen) ? 0u : stall + 1u;
+        seen = now;
+        ws.longest_stall = max(ws.longest_stall, stall);
+        if (stall > q.max_polls || queue_load(q.error) != 0u) { ok = false; break; }
     }
+    ws.longest_wait = max(ws.longest_wait, polls);
+    return ok;
 }
 
 __device__ __forceinline__ unsigned queue_take_ticket(const QueueArgs& q, int lane)
@@ -1603,18 +1627,19 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
     const int lane = threadIdx.x;
     const unsigned G = (unsigned)q.n_groups;
     const unsigned n_tasks = (unsigned)q.n_pairs * G;
+    QueueWaitStats ws = {0u, 0u, 0u};
     unsigned k = queue_take_ticket(q, lane);
     while (k < n_tasks) {
         const int pair = (int)(k / G), g = (int)(k % G);
         const int s = __builtin_amdgcn_readfirstlane(q.task_reach[pair]);
         const int c = __builtin_amdgcn_readfirstlane(q.task_chunk[pair]);
         bool ok = true;                       // everything here is wave-uniform
-        if (c > 0) ok = queue_wait(q, &q.done[(size_t)s * G + g], (unsigned)c);
+        if (c > 0) ok = queue_wait(q, &q.done[(size_t)s * G + g], (unsigned)c, ws);
         for (int i = a.up_ptr[s]; ok && i < a.up_ptr[s + 1]; ++i)
-            ok = queue_wait(q, &q.done[(size_t)a.up_idx[i] * G + g], (unsigned)(c + 1));
+            ok = queue_wait(q, &q.done[(size_t)a.up_idx[i] * G + g], (unsigned)(c + 1), ws);
         if (c >= q.ring_chunks)
             for (int i = q.down_ptr[s]; ok && i < q.down_ptr[s + 1]; ++i)
-                ok = queue_wait(q, &q.done[(size_t)q.down_idx[i] * G + g], (unsigned)(c - q.ring_chunks + 1));
+                ok = queue_wait(q, &q.done[(size_t)q.down_idx[i] * G + g], (unsigned)(c - q.ring_chunks + 1), ws);
         if (ok) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1625,8 +1650,10 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
+            if (lane == 0) {
                 __hip_atomic_store(&q.done[(size_t)s * G + g], (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(q.progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // what waiting waves watch
+            }
             if (q.chunk_count) {
                 // every task adds to its chunk's counter AFTER its own release (above: the XCD's L2 has been written back and
                 // the wait has drained), so when the last add arrives all rows of the chunk are in memory, where the copy engine
@@ -1640,8 +1667,13 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
             k = queue_take_ticket(q, lane);
         } else {
             if (lane == 0) __hip_atomic_store(q.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            k = n_tasks;                      // a wait timed out (or another wave raised the error flag): drain
+            k = n_tasks;                      // a wait found the run stalled (or another wave raised the error flag): drain
         }
+    }
+    if (lane == 0 && ws.waits) {
+        atomicAdd(&a.counters[4], (unsigned long long)ws.waits);
+        atomicMax(&a.counters[5], (unsigned long long)ws.longest_wait);
+        atomicMax(&a.counters[6], (unsigned long long)ws.longest_stall);
     }
 }
 

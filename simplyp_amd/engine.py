@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, 'simplyp_hip.hip'), os.path.join(CSRC, 'simplyp_kernels.hip.h'),
             os.path.join(CSRC, 'simplyp_gof.hip.h'), os.path.join(CSRC, 'simplyp_waterbody.hip.h'),
-            os.path.join(INCLUDE, 'simplyp.h')]
+            os.path.join(INCLUDE, 'simplyp.h'), os.path.join(INCLUDE, 'simplyp_controller.h')]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -327,9 +327,13 @@ class Engine(object):
         with torch.cuda.device(self.tdev):
             self._bind_stream()
             ip = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.POINTER(C.c_int32))
+            # the arm is one-shot and consumed by the next run whatever its outcome; disarming explicitly when no host table is
+            # wanted keeps this context safe even against an arm left by another user of the same handle
             if host_out is not None:
                 self._check(L.simplyp_stream_out(self._h, C.c_void_p(host_out.ctypes.data), C.c_int64(host_out.nbytes)),
                             'simplyp_stream_out')
+            else:
+                self._check(L.simplyp_stream_out(self._h, None, C.c_int64(0)), 'simplyp_stream_out')
             args = (self._h, C.byref(dims), C.byref(opts), f.data_ptr(), dy.data_ptr(),
                     None if pod is None else pod.data_ptr(),
                     None if fom is None else fom.data_ptr(), mp.data_ptr(), rp.data_ptr(),

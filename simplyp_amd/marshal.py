@@ -41,18 +41,23 @@ NONODE_COLUMNS = ['Qq', 'QsA', 'QsS', 'Qg', 'C_cover_A', 'EPC0_A_kgmm', 'EPC0_NC
                   'TDPs_A_kg', 'P_labile_A_kg', 'conc_TDPs_A_kgmm',
                   'TDPs_NC_kgmm', 'P_labile_NC_kg', 'conc_TDPs_NC_kgmm']
 OUT_COLUMNS = ODE_COLUMNS + NONODE_COLUMNS
-N_OUT = len(OUT_COLUMNS)
+N_OUT = len(OUT_COLUMNS)            # the reference's 25 columns (SIMPLYP_N_OUT_REF)
 MASK_ALL = (1 << N_OUT) - 1
+# 26th column (SIMPLYP_OUT_D_SNOW), only when the snow module runs inside the kernel (opts.snow): the member's snow depth at
+# the end of the day = met_df['D_snow_end'] (inputs.py:197-207), which the reference returns as df_TC['D_snow'] (model.py:775-776)
+SNOW_COLUMN = 'D_snow'
+ALL_COLUMNS = OUT_COLUMNS + [SNOW_COLUMN]
+MASK_D_SNOW = 1 << ALL_COLUMNS.index(SNOW_COLUMN)
 REACH5_COLUMNS = ['Vr', 'Qr', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day']     # model.py:272-277
 MASK_REACH5 = sum(1 << OUT_COLUMNS.index(c) for c in REACH5_COLUMNS)
 
 
 def columns_of_mask(mask):
-    return [c for i, c in enumerate(OUT_COLUMNS) if (mask >> i) & 1]
+    return [c for i, c in enumerate(ALL_COLUMNS) if (mask >> i) & 1]
 
 
 def mask_of_columns(cols):
-    return sum(1 << OUT_COLUMNS.index(c) for c in cols)
+    return sum(1 << ALL_COLUMNS.index(c) for c in cols)
 
 
 def sc_list(p):

@@ -145,13 +145,35 @@ def _kf_last(p_SU, p_LU, p_SC, p):
     return p['Kf']
 
 
+
+def _output_dict(stats, status, solver):
+    """The 4th return value.  The reference hands back LSODA's infodict of its LAST odeint call (model.py:640, :827: last
+    sub-catchment, last day) -- arrays of one element under 'nst', 'nfe', 'nje', 'hu', ..., and 'message'.  LSODA is not what
+    integrates here, so the engine's own statistics are returned, and the keys a caller of the reference could have read are
+    kept as aliases with the same types: 'nfe' (right-hand-side evaluations), 'nst' (accepted steps), 'nje' (Jacobian
+    evaluations: none, the pair is explicit) as one-element int32 arrays -- totals over the whole run, not the last day's
+    call --, 'mused' (1 = non-stiff method) and 'message' ('Integration successful.' unless the member was flagged)."""
+    msg = 'Integration successful.'
+    if status & abi.STATUS_NONFINITE:
+        msg = 'Non-finite state met (member status %d); results from that day on are NaN.' % status
+    elif status & abi.STATUS_STEPCAP:
+        msg = 'Excess work done on a day (max_steps attempts; member status %d).' % status
+    d = dict(stats, member_status=status, solver=dict(abi.DEFAULT_SOLVER, **(solver or {})), engine='MI355X batched engine',
+             message=msg)
+    d['nfe'] = np.array([stats['rhs_evals']], dtype=np.int32)
+    d['nst'] = np.array([stats['steps']], dtype=np.int32)
+    d['nje'] = np.array([0], dtype=np.int32)
+    d['mused'] = np.array([1], dtype=np.int32)
+    return d
+
 def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len=1., solver=None, device=0):
     """Simple hydrology, sediment and phosphorus model (reference model.py:193-827).
 
     Same arguments and 4-tuple return ``(df_TC_dict, df_R_dict, Kf, output_dict)`` as the
     reference.  Extra keyword arguments: ``solver`` (dict overriding ``abi.DEFAULT_SOLVER``:
     integrator 'cashkarp'|'rk4', rtol, atol, substeps, max_steps, project_vr) and ``device``.
-    ``output_dict`` holds the engine's solver statistics instead of LSODA's infodict.
+    ``output_dict`` holds the engine's solver statistics, with LSODA's infodict keys ``nfe``, ``nst``, ``nje``, ``mused``,
+    ``message`` kept as aliases (``_output_dict``).
     """
     from . import engine
 
@@ -223,10 +245,31 @@ def run_simply_p(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, step_len
             df_R_toSave.to_csv(os.path.join(out_dir, "Instream_results_Reach%s.csv" % SC))
         print('Results saved to csv\n')
 
-    output_dict = dict(stats, member_status=status, solver=dict(abi.DEFAULT_SOLVER, **(solver or {})),
-                       message='MI355X batched engine')
+    output_dict = _output_dict(stats, status, solver)
     return (df_TC_dict, df_R_dict, Kf, output_dict)                                          # :827
 
+
+
+def _host_table(shape, pin):
+    """Host array that receives an ensemble's output table: page-locked (the streamed copies then run at PCIe speed beside the
+    kernel) when the host can lock that much -- not more than 60 % of what it has available, the guard bench.py applies --
+    else an ordinary pageable array, which ``simplyp_stream_out`` accepts too (slower copies, same table)."""
+    from . import engine
+    nbytes = int(np.prod(shape, dtype=np.int64)) * 8
+    avail = None
+    try:
+        with open('/proc/meminfo') as fh:
+            for line in fh:
+                if line.startswith('MemAvailable:'):
+                    avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    if avail is None or nbytes <= 0.6 * avail:
+        try:
+            return pin(shape)
+        except engine.EngineError:
+            pass
+    return np.empty(shape, dtype=np.float64)
 
 def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
                           outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True,
@@ -237,7 +280,8 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
     array broadcastable to [S, E] (reach parameters, ``marshal.PR_NAMES``); parameters not
     listed take the workbook value for every member.  ``outputs``: list of reference column
-    names (default: the five documented reach outputs, model.py:272-277).  ``out_reaches``:
+    names (default: the five documented reach outputs, model.py:272-277); with the in-kernel snow module also ``'D_snow'``,
+    every member's snow depth at the end of the day (what the reference returns as ``df_TC['D_snow']``, model.py:775-776).  ``out_reaches``:
     sub-catchment ids to return (default all).  ``reduce``: None for daily rows, ``'annual'`` for one row
     per calendar year holding the sum of that year's daily values (e.g. annual fluxes), or an int array
     [D] of period indices; the periods are returned under ``'periods'``.
@@ -326,6 +370,9 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
             raise ValueError("goodness of fit needs the daily series: obs_dict cannot be combined with reduce")
         cols += [c for c in ('Qr', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day') if c not in cols]
     mask = marshal.mask_of_columns(cols)
+    if mask & marshal.MASK_D_SNOW and not snow_in_kernel:
+        raise ValueError("output 'D_snow' is the per-member snow depth of the in-kernel snow module: needs snow_in_kernel=True "
+                         "(without it every member shares met_df['D_snow_end'])")
     period_of_day, periods = None, None
     if reduce is not None:
         if isinstance(reduce, str):
@@ -351,7 +398,7 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     if to_host and (keep_daily or obs_dict is None):
         n_or_ = len(scs) if oreach is None else len(oreach)
         rows_ = len(met_df) if periods is None else len(periods)
-        host_out = pin((bin(mask).count('1'), rows_, n_or_, E))
+        host_out = _host_table((bin(mask).count('1'), rows_, n_or_, E), pin)
     out_d, status_d, stats = eng.run(forcing, doy, mp, rp_d, up_ptr, up_idx, opts, out_reaches=oreach,
                                      period_of_day=period_of_day, forcing_of_member=forcing_of_member, host_out=host_out)
     marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)

@@ -1,7 +1,7 @@
 """Synthetic ensembles on the Tarland example (the BASELINE.json configurations).
 
 Everything starts from the reference's shipped parameter workbook and 30-year met file (data copies
-under tests/golden/reference_data/, read through the package's own read_input_data), so the bench and
+under data/ at the repository root, read through the package's own read_input_data), so the bench and
 the full-size tests go through the same host path a user's notebook would.
 """
 
@@ -12,9 +12,12 @@ import numpy as np
 from . import inputs, marshal
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_DATA = os.path.join(REPO, 'tests', 'golden', 'reference_data')
+REF_DATA = os.path.join(REPO, 'data')
 WORKBOOK = os.path.join(REF_DATA, 'Parameters_v0-2A_Tarland.xlsx')
 MET_CSV = os.path.join(REF_DATA, 'Tarland_MetData_1981-2010.csv')
+
+Q_OBS = os.path.join(REF_DATA, 'Coull_DailyMeanQ.xlsx')
+CHEM_OBS = os.path.join(REF_DATA, 'Coull_ChemObs.xlsx')
 
 C3_SEED = 20240601
 
@@ -28,6 +31,17 @@ def tarland_inputs(st_dt='1981-01-01', end_dt='2010-12-31', dynamic_epc0='y', dy
     with (contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()):
         p_SU, dyn, p, p_LU, p_SC, p_struc, met_df, _ = inputs.read_input_data(WORKBOOK, setup_overrides=over)
     return met_df, p_struc, p_SU, p_LU, p_SC, p, dyn
+
+
+def tarland_observations(st_dt='1981-01-01', end_dt='2010-12-31'):
+    """obs_dict (sub-catchment -> DataFrame of observed Q / SS / TDP / PP / TP / SRP) of the Tarland example for a period,
+    as the package's read_input_data returns it from the shipped observation workbooks (reference inputs.py:118-152)."""
+    import contextlib
+    import io
+    over = dict(metdata_fpath=MET_CSV, Qobsdata_fpath=Q_OBS, chemObsData_fpath=CHEM_OBS, st_dt=st_dt, end_dt=end_dt)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obs_dict = inputs.read_input_data(WORKBOOK, setup_overrides=over)[7]
+    return obs_dict
 
 
 def monte_carlo_overrides(p, p_LU, n_members, seed=C3_SEED):

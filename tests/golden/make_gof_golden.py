@@ -7,7 +7,7 @@ Runs only in the build container (needs /root/reference).  visualise_results.py 
 with numpy / pandas / os in scope; nothing of its text is written anywhere.  ``.ix`` is shimmed as in make_golden.py.
 
 Inputs: the golden reach tables (df_R of the reference at rtol=atol=1e-12 and as shipped) already in this directory,
-and the observations the reference ships (reference_data/Coull_*.xlsx, read by simplyp_amd.xlsx), truncated to the
+and the observations the reference ships (data/Coull_*.xlsx, read by simplyp_amd.xlsx), truncated to the
 run period exactly as the reference's read_input_data does (inputs.py:118-152).
 
 Also records, for a few perturbed simulated series (sim * fixed smooth factors; no reference model run needed: the

@@ -15,7 +15,7 @@ How the reference is driven:
     either as shipped (rtol=0.01, default atol, mxstep=5000) or at rtol=atol=1e-12
     ("tight": the converged solution of the reference's own equations = the parity oracle).
 
-Usage:  python tests/golden/make_golden.py [--long]
+Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout]
 """
 
 import argparse
@@ -355,11 +355,71 @@ def monte_carlo_members(mods, switch, n=8, years=('2003-01-01', '2005-12-31')):
     np.savez_compressed(os.path.join(HERE, 'monte_carlo_members.npz'), **arrays)
 
 
+# Members of the 100 000-member C3 bench ensemble whose worst day, under a plain relative-tolerance controller, was a step across a
+# knee of one of the reference's smooth-step gates (tests/test_oracle_series.py::KNEE_MEMBERS): the members the constants of
+# the knee-aware step controller were tuned on.  Their reference-made tables pin the tuned controller to the reference.
+KNEE_MEMBERS = [53752, 60773, 37627, 41834, 71711, 27305]
+REACH_COLS = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
+
+
+def _member_worker(job):
+    """One member of the C3 distribution through the unmodified reference at rtol=atol=1e-12 (own process: the reference
+    is single-threaded Python).  job = (seed, n_draw, member, st_dt, end_dt)."""
+    seed, n_draw, member, st_dt, end_dt = job
+    from simplyp_amd import synthetic, marshal
+    mods = load_reference()
+    switch = OdeintSwitch()
+    mods['model'].odeint = switch
+    p_SU, p, p_LU, p_SC, p_struc, met = tarland_inputs(st_dt, end_dt)
+    over = synthetic.monte_carlo_overrides(p, p_LU, n_draw, seed=seed)
+    sc = dict(p_SU=p_SU, p=p.copy(), p_LU=p_LU.copy(), p_SC=p_SC, p_struc=p_struc, met=met,
+              dyn=dict(Dynamic_EPC0='y', Dynamic_erodibility='n'))
+    for name in over:
+        src = dict(marshal.PM_SPEC)[name]
+        if src[0] == 'p':
+            sc['p'][src[1]] = float(over[name][member])
+        else:
+            sc['p_LU'].loc[src[1], src[2]] = float(over[name][member])
+    r = run_reference(mods, switch, sc, 1e-12)
+    R = r['df_R'][1]
+    print('seed %d member %d: wall %.1f s  nfe/day %.1f' % (seed, member, r['wall'], r['nfe_per_day']), flush=True)
+    return (member, R[REACH_COLS].to_numpy(dtype=float), {k: float(over[k][member]) for k in sorted(over)})
+
+
+def members_fixture(fname, seed, n_draw, members, st_dt, end_dt, n_proc):
+    """`members` of the n_draw-member C3 draw with `seed`, each over [st_dt, end_dt], 9 reach columns -> fname."""
+    import multiprocessing as mp
+    jobs = [(seed, n_draw, int(m), st_dt, end_dt) for m in members]
+    with mp.get_context('fork').Pool(min(n_proc, len(jobs))) as pool:
+        res = pool.map(_member_worker, jobs, chunksize=1)
+    arrays = {'members': np.array([m for m, _, _ in res]), 'seed': np.array(seed), 'n_draw': np.array(n_draw),
+              'years': np.array([st_dt, end_dt]), 'columns': np.array(REACH_COLS),
+              'names': np.array(sorted(res[0][2])),
+              'values': np.array([[ov[k] for (_, _, ov) in res] for k in sorted(res[0][2])])}
+    for m, R, _ in res:
+        arrays['R/%d' % m] = R
+    np.savez_compressed(os.path.join(HERE, fname), **arrays)
+    print(fname, 'written')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--long', action='store_true', help='also run the 1981-2010 scenario (minutes)')
     ap.add_argument('--only', default=None)
+    ap.add_argument('--procs', type=int, default=6, help='worker processes of the per-member fixtures (knee, heldout)')
     args = ap.parse_args()
+
+    if args.only == 'knee':
+        # the six members the knee-aware controller was tuned on: the whole 30 years (their worst days under the plain and
+        # the knee-aware controller lie between 1982 and 2005)
+        from simplyp_amd import synthetic
+        members_fixture('knee_members.npz', synthetic.C3_SEED, 100000, KNEE_MEMBERS, '1981-01-01', '2010-12-31', args.procs)
+        return
+    if args.only == 'heldout':
+        # 16 members of a draw nothing was tuned on (seed C3_SEED + 7: what rank 7 of a weak-scaling bench runs), 3 years
+        from simplyp_amd import synthetic
+        members_fixture('heldout_members.npz', synthetic.C3_SEED + 7, 16, range(16), '2003-01-01', '2005-12-31', args.procs)
+        return
 
     mods = load_reference()
     switch = OdeintSwitch()

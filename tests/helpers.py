@@ -8,6 +8,7 @@ import numpy as np
 import pandas as pd
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'data')      # the reference's shipped data files (workbook, met series, observations, example outputs)
 _meta = None
 
 
@@ -89,12 +90,12 @@ def marshal_scenario(name, E=1, out_mask=None, solver=None, snow=False):
 
 
 def observations(st_dt, end_dt):
-    """obs_dict of the shipped Tarland observation workbooks (tests/golden/reference_data), truncated to the run
+    """obs_dict of the shipped Tarland observation workbooks (data/ at the repository root), truncated to the run
     period the way the reference's read_input_data does (inputs.py:118-152)."""
     from simplyp_amd import xlsx
     df_li = []
     for f in ('Coull_DailyMeanQ.xlsx', 'Coull_ChemObs.xlsx'):
-        wb = xlsx.Workbook(os.path.join(GOLDEN, 'reference_data', f))
+        wb = xlsx.Workbook(os.path.join(DATA, f))
         df = xlsx.read_excel(wb, '1', index_col=0)
         df.index = pd.to_datetime(df.index)
         df_li.append(df.sort_index().truncate(before=st_dt, after=end_dt))
@@ -122,3 +123,31 @@ def _working_tolerance():
 
 
 TOL_WORKING = _working_tolerance()
+
+
+def member_fixture_problem(fname, solver=None):
+    """Arrays + opts for the members of a per-member reference fixture (tests/golden/knee_members.npz, heldout_members.npz:
+    members of a C3-distribution draw run one by one through the unmodified reference at rtol=atol=1e-12 by
+    tests/golden/make_golden.py) and their reference tables: (problem dict, [table[D, 9 reach columns] per member]).
+    The parameter values are regenerated from the recorded seed and checked against what the fixture recorded."""
+    from simplyp_amd import synthetic, marshal, abi
+    z = np.load(os.path.join(GOLDEN, fname), allow_pickle=False)
+    members = [int(m) for m in z['members']]
+    years = [str(y) for y in z['years']]
+    met_df, p_struc, p_SU, p_LU, p_SC, p, dyn = synthetic.tarland_inputs(years[0], years[1], dynamic_epc0='y', dynamic_erod='n')
+    over_all = synthetic.monte_carlo_overrides(p, p_LU, int(z['n_draw']), seed=int(z['seed']))
+    over = {k: v[members] for k, v in over_all.items()}
+    for k, nm in enumerate(str(n) for n in z['names']):                # the generator still draws what the fixture recorded
+        np.testing.assert_array_equal(over[nm], z['values'][k])
+    marshal.prologue(p_SU, p_LU, p_SC, p)
+    up_ptr, up_idx, _ = marshal.topology(p_struc, p)
+    n = len(members)
+    mp = marshal.member_params(p, p_LU, n, over)
+    rp = marshal.reach_params(p_SC, p, n)
+    forcing, doy = marshal.forcing_arrays(met_df)
+    opts = abi.make_opts(solver, dynamic_epc0=True, run_mode_cal=True)
+    assert [str(c) for c in z['columns']] == ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay',
+                                              'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
+    tables = [z['R/%d' % m] for m in members]
+    return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx, opts=opts,
+                members=members, met=met_df), tables

@@ -36,6 +36,31 @@ def perturbed(name, E, seed=3, **kw):
     return m
 
 
+def raw_run(eng, m, out=None):
+    """simplyp_run straight through the C ABI (device buffers via torch), WITHOUT Engine.run's own simplyp_stream_out call:
+    what a C caller does.  Returns (rc, out tensor)."""
+    import torch
+    L = engine.lib()
+    o = m['opts']
+    dev = [eng.to_device(m['forcing'], torch.float64), eng.to_device(m['doy'], torch.int32),
+           eng.to_device(m['member_params'], torch.float64), eng.to_device(m['reach_params'], torch.float64)]
+    n_sets, _, D = dev[0].shape
+    _, S, E = dev[3].shape
+    if out is None:
+        out = torch.empty((bin(o.out_mask).count('1'), D, S, E), dtype=torch.float64, device=eng.tdev)
+    status = torch.empty((E,), dtype=torch.int32, device=eng.tdev)
+    up_ptr = np.ascontiguousarray(m['up_ptr'], dtype=np.int32); up_idx = np.ascontiguousarray(m['up_idx'], dtype=np.int32)
+    ip = lambda a: None if a.size == 0 else a.ctypes.data_as(C.POINTER(C.c_int32))
+    torch.cuda.synchronize()
+    dims = abi.Dims(E, S, D, n_sets)
+    stats = abi.Stats()
+    assert L.simplyp_ctx_set_stream(eng._h, None) == 0
+    rc = L.simplyp_run(eng._h, C.byref(dims), C.byref(o), dev[0].data_ptr(), dev[1].data_ptr(), None, None, dev[2].data_ptr(),
+                       dev[3].data_ptr(), ip(up_ptr), ip(up_idx), None, S, out.data_ptr(), status.data_ptr(), None, None,
+                       C.byref(stats))
+    return rc, out
+
+
 @pytest.mark.parametrize('name,E,solver,expect_queue', [
     ('tarland_1981_2010_dynamic', 700, None, True),                             # 172 chunks of 64 days, copies beside the kernel
     ('tarland_1981_2010_dynamic', 130, dict(time_chunk_days=512), True),        # longer chunks
@@ -80,26 +105,6 @@ def test_copies_overlap_the_kernel_on_a_long_run(engine0):
     assert np.array_equal(host, out.cpu().numpy(), equal_nan=True)
 
 
-@pytest.mark.parametrize('group', [3, 4, 1000])
-def test_several_chunks_per_copy(engine0, group, monkeypatch):
-    """Fewer, larger copies (SIMPLYP_COPY_GROUP, a diagnostic): chunks [c, c + group) of a column travel as one copy, the
-    ragged last group and the ragged last chunk included; the host table equals the device table and the run reports what it
-    did."""
-    m = perturbed('tarland_1981_2010_dynamic', 700, out_mask=marshal.MASK_REACH5)
-    shape = (5, m['forcing'].shape[2], 1, 700)
-    host = engine.pinned_empty(shape)
-    host[...] = -1.0
-    monkeypatch.setenv('SIMPLYP_COPY_GROUP', str(group))
-    out, status, st = run(engine0, m, host_out=host)
-    monkeypatch.delenv('SIMPLYP_COPY_GROUP')
-    assert st['queued'] == 1 and st['copy_group'] == min(group, 64) and st['stream_gbs'] > 0, st
-    assert np.array_equal(host, out.cpu().numpy(), equal_nan=True)
-    host[...] = -1.0
-    out, status, st = run(engine0, m, host_out=host)              # (the variable is read per run)
-    assert st['copy_group'] == 1, st
-    assert np.array_equal(host, out.cpu().numpy(), equal_nan=True)
-
-
 def test_time_reduced_rows_and_slot_order_are_streamed_too(engine0):
     m = perturbed('tarland_1981_2010_dynamic', 300, out_mask=marshal.mask_of_columns(['Qr', 'TDP_kg/day']),
                   solver=dict(out_slot_order=1, balance=1))
@@ -125,11 +130,68 @@ def test_pageable_host_buffer_and_argument_errors(engine0):
     L = engine.lib()
     small = engine.pinned_empty((100,))
     assert L.simplyp_stream_out(engine0._h, C.c_void_p(small.ctypes.data), C.c_int64(small.nbytes)) == 0
-    with pytest.raises(engine.EngineError, match='smaller than the output table'):
-        run(engine0, m)
-    out2, _, _ = run(engine0, m)
+    rc, _ = raw_run(engine0, m)
+    assert rc == -1 and b'smaller than the output table' in L.simplyp_last_error(engine0._h)
+    rc, out2 = raw_run(engine0, m)
     import torch
-    assert bool(torch.equal(out, out2))
+    assert rc == 0 and bool(torch.equal(out, out2))
+
+
+def test_a_refused_run_spends_the_arm(engine0):
+    """simplyp_stream_out is one-shot whatever becomes of the next run.  A run refused for its arguments (rtol <= 0:
+    check_args) must not leave the arm behind -- the caller drops the buffer, and the next plain run on the cached context
+    would stream its whole table into freed memory.  Straight through the C ABI (Engine.run disarms by itself)."""
+    import torch
+    L = engine.lib()
+    m = perturbed('tarland_2004_dynamic', 64, out_mask=marshal.MASK_REACH5)
+    host = engine.pinned_empty((5, 366, 1, 64))
+    host[...] = -3.0
+    assert L.simplyp_stream_out(engine0._h, C.c_void_p(host.ctypes.data), C.c_int64(host.nbytes)) == 0
+    good_rtol = m['opts'].rtol
+    m['opts'].rtol = -1.0
+    rc, _ = raw_run(engine0, m)
+    assert rc == -1 and b'rtol' in L.simplyp_last_error(engine0._h)
+    m['opts'].rtol = good_rtol
+    rc, out = raw_run(engine0, m)                              # a plain run: nothing armed any more
+    assert rc == 0 and bool(torch.isfinite(out).all())
+    assert float(host.max()) == -3.0 and float(host.min()) == -3.0
+    # and the Engine wrapper disarms whatever another user of the handle left armed
+    assert L.simplyp_stream_out(engine0._h, C.c_void_p(host.ctypes.data), C.c_int64(host.nbytes)) == 0
+    out2, _, _ = run(engine0, m)
+    assert bool(torch.equal(out, out2)) and float(host.max()) == -3.0 and float(host.min()) == -3.0
+
+
+def test_queue_waits_are_bounded_by_lack_of_progress_not_by_time(engine0, monkeypatch):
+    """The task queue's dependency waits fail only when NO task of the run completes for SIMPLYP_QUEUE_MAX_POLLS polls -- not
+    when a wait is merely long.  2 048 members streamed in 1 024-day chunks (one task ~ 20 ms ~ 10 000 polls of ~2 us): waves
+    that finish a chunk early wait milliseconds for the owner of their group's previous chunk.  With the bound at 500 polls
+    (far below one task, let alone the longest wait) the run must complete and equal the default run bit for bit; its
+    statistics show waits longer than the bound (which the poll-counting rule of rounds 1-2 would have failed) and no
+    stall anywhere near it.  And a genuine stall still raises the error path (every worker drains, simplyp_sync reports it,
+    the context stays usable)."""
+    import torch
+    m = perturbed('tarland_1981_2010_dynamic', 2048, out_mask=marshal.MASK_REACH5, solver=dict(time_chunk_days=1024))
+    host = engine.pinned_empty((5, m['forcing'].shape[2], 1, 2048))
+    ref, ref_status, st0 = run(engine0, m, host_out=host)
+    assert st0['queued'] == 1 and st0['queue_waits'] > 0
+    monkeypatch.setenv('SIMPLYP_QUEUE_MAX_POLLS', '500')
+    host[...] = -1.0
+    out, status, st = run(engine0, m, host_out=host)
+    assert st['queued'] == 1 and bool(torch.equal(out, ref)) and bool(torch.equal(status, ref_status))
+    assert np.array_equal(host, ref.cpu().numpy(), equal_nan=True)
+    assert st['queue_longest_wait_polls'] > 500, st            # a wait that outlasted the bound ...
+    assert st['queue_longest_stall_polls'] <= 500, st          # ... while tasks kept completing all over the chip
+    # one member group only: the 172 chunk tasks are taken by 172 waves at once and form a serial chain -- every wait lasts as
+    # long as its predecessor's task (hundreds of polls) with nothing else completing meanwhile: a genuine stall for a bound of 5
+    monkeypatch.setenv('SIMPLYP_QUEUE_MAX_POLLS', '5')
+    m2 = perturbed('tarland_1981_2010_dynamic', 8, out_mask=marshal.MASK_REACH5, solver=dict(time_chunk_days=64))
+    with pytest.raises(engine.EngineError, match='no task of the run completed'):
+        run(engine0, m2)
+    monkeypatch.delenv('SIMPLYP_QUEUE_MAX_POLLS')
+    out2, status2, st2 = run(engine0, m2)                      # the same run with the default bound: completes
+    assert st2['queued'] == 1 and int(status2.max()) == 0 and st2['queue_longest_stall_polls'] > 5, st2
+    out, status, _ = run(engine0, m, host_out=host)            # the context is usable afterwards
+    assert bool(torch.equal(out, ref))
 
 
 def test_inputs_still_in_flight_on_torchs_default_stream(engine0):
@@ -219,27 +281,55 @@ def test_config_c3_at_100k_members_through_the_benched_path(engine0, oracle_lib)
 
 def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` from a plain shell: the parent must spawn its ranks before touching the GPU (gloo
-    rehearsal: two ranks share this box's one GPU) and relay rank 0's JSON line; weak and strong scaling.
-    The rehearsal leaves the table in HBM (--no-stream) and is small enough for the chain kernel: two PROCESSES on one GPU
-    are time-sliced by the driver, and two persistent task-queue kernels with hundreds of copy dispatches in between then
-    crawl (35 s per pass measured, one wave-wait timeout) -- an artefact of sharing the card that one rank per GPU does not
-    have; the streamed path is covered single-rank above."""
+    rehearsal: two ranks share this box's one GPU) and relay rank 0's ONE JSON line.  Default scaling = strong (BASELINE C3 is
+    one ensemble split over the GPUs): members_total stays what was asked for; the line carries cpu_baseline at world size 2,
+    per-rank kernel times and the collective's rank count (0 here: gloo rehearsal, no RCCL).  The tables are streamed to
+    pinned host memory by both ranks at once -- two PROCESSES whose persistent task-queue kernels share one GPU: slow (the
+    waves of both kernels compete for the same SIMDs), which the queue's progress-based wait bound tolerates (round 2 had a
+    poll-count bound and this rehearsal once failed with a wait "timeout")."""
     import json
     env = dict(os.environ, SIMPLYP_BENCH_BACKEND='gloo')
     env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
-    for scaling, per_gpu, total in (('weak', 1500, 3000), ('strong', 1500, 3000)):
+    for scaling, per_gpu, total in ((None, 1500, 3000), ('weak', 1500, 3000)):
         members = per_gpu if scaling == 'weak' else total
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
-                            '--members', str(members), '--scaling', scaling, '--no-cpu-baseline', '--no-stream'],
-                           env=env, capture_output=True, text=True, timeout=900)
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--members', str(members)]
+        cmd += ['--scaling', scaling, '--no-cpu-baseline'] if scaling else []
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
         assert len(lines) == 1
         j = json.loads(lines[0])
-        assert j['n_gpus'] == 2 and j['scaling'] == scaling
-        assert j['config']['members_total'] == total and j['config']['members_per_gpu'] == per_gpu
+        assert j['n_gpus'] == 2 and j['scaling'] == (scaling or 'strong')
+        assert j['members_total'] == j['config']['members_total'] == total and j['config']['members_per_gpu'] == per_gpu
         assert j['value'] > 0 and j['parity']['timed_run_sample']['max_rel_err_vs_oracle'] < helpers.TOL_WORKING
-        assert j['transfer']['streamed_chunks'] == 0 and j['value_device_resident'] is None
+        assert j['parity']['timed_run_sample']['host_table_equals_device_table'] is True and j['value_device_resident'] > 0
+        assert len(j['per_rank']['kernel_ms']) == 2 and min(j['per_rank']['kernel_ms']) > 0
+        assert j['rccl_ranks'] == 0 and 'gloo' in j['collective_backend']
+        if scaling is None:
+            assert j['cpu_baseline']['value'] > 0 and j['cpu_baseline']['cores'] >= 1
+            assert j['parity']['golden']['knee_members']['worst_member_max_rel_err'] < 1e-6
+            assert j['parity']['golden']['heldout_members']['worst_member_max_rel_err'] < 5e-7
+
+
+def test_default_bench_line_carries_the_secondary_legs(tmp_path):
+    """The driver's `python bench.py` (N = 1, no flags): the headline C3 line plus, after the timed region, BASELINE C2 and C5
+    and the goodness-of-fit-only pass, cpu_baseline, value_weak (= value at N = 1).  Run here with 1 step."""
+    import json
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 1 and j['scaling'] == 'strong' and j['members_total'] == 100000 and j['rccl_ranks'] == 1
+    assert j['roofline']['frac'] > 0.01 and j['cpu_baseline']['kind'] == 'port' and j['members_flagged'] == 0
+    sec = j['secondary']
+    assert sec['c2']['replicas_bit_identical'] is True and sec['c2']['host_rows_equal'] is True and sec['c2']['lanes_per_member'] >= 4
+    assert sec['c5']['parity_grade'] is False and sec['c5']['value'] > j['value']
+    assert sec['c3_gof_only']['value'] > j['value'] and sec['c3_gof_only']['gof_ms'] > 0 and sec['c3_gof_only']['best_member_nse_q'] > 0.0
+    assert j['value_weak']['same_run_as_value'] is True and j['value_weak']['value'] == j['value']
 
 
 @pytest.mark.parametrize('lanes', [1, 13, 32])

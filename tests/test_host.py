@@ -12,7 +12,7 @@ import helpers
 import simplyp_amd as sp
 from simplyp_amd import marshal, xlsx, engine, abi
 
-REF_DATA = os.path.join(helpers.GOLDEN, 'reference_data')
+REF_DATA = helpers.DATA
 WORKBOOK = os.path.join(REF_DATA, 'Parameters_v0-2A_Tarland.xlsx')
 
 

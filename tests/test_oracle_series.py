@@ -104,7 +104,7 @@ def test_oracle_vs_reference_as_shipped(oracle_lib, name):
 def test_oracle_vs_shipped_example_output_csv(oracle_lib):
     """The two result files the reference ships (Example_Data/Example_Output): reproduced to the ~3e-3 that
     LSODA at rtol=0.01 allows (the unmodified reference itself re-run here only gets 1e-3..3.4e-3)."""
-    ref_dir = os.path.join(helpers.GOLDEN, 'reference_data')
+    ref_dir = helpers.DATA
     csv_R = pd.read_csv(os.path.join(ref_dir, 'Instream_results_Reach1.csv'), index_col=0)
     csv_TC = pd.read_csv(os.path.join(ref_dir, 'Results_TC_SC1.csv'), index_col=0)
     m = helpers.marshal_scenario('tarland_2004_dynamic')
@@ -229,3 +229,18 @@ def test_knee_aware_controller_on_the_members_that_needed_it(oracle_lib):
     assert worst.max() < 5e-7, dict(zip(KNEE_MEMBERS, worst))
     # (these are low-flow members: fewer steps than the ensemble's 87 right-hand sides per catchment-day)
     assert 55 < stats['rhs_evals'] / (len(KNEE_MEMBERS) * D) < 95
+
+
+@pytest.mark.parametrize('fname,bar', [('knee_members.npz', 1e-6), ('heldout_members.npz', 5e-7)])
+def test_oracle_default_solver_against_reference_tables_of_single_members(oracle_lib, fname, bar):
+    """The CPU mirror of the kernel's default solver against reference-made tables of single members (the unmodified reference
+    at rtol=atol=1e-12, tests/golden/make_golden.py --only knee | heldout): the six members the knee-aware controller was tuned
+    on (30 years) and 16 members of a held-out draw (3 years); north_star's bar on all 9 reach outputs.  The same fixtures are
+    run through the HIP kernel in tests/test_gpu_parity.py."""
+    m, tables = helpers.member_fixture_problem(fname)
+    out, status, _ = oracle_lib.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'],
+                                    n_threads=8)
+    assert status.max() == 0
+    worst = [max(helpers.max_rel_err(out[marshal.OUT_COLUMNS.index(c), :, 0, k], tables[k][:, j], floor=1e-300)
+                 for j, c in enumerate(REACH_COLS)) for k in range(len(tables))]
+    assert max(worst) < bar, dict(zip(m['members'], worst))

@@ -108,3 +108,62 @@ def test_run_simply_p_ensemble_perturbs_snow_parameters(engine0):
         assert np.array_equal(res['data'][..., k], one['data'][..., 0])
     with pytest.raises(ValueError, match='Precipitation'):
         sp.run_simply_p_ensemble(met[['P', 'PET']].copy(), *args()[1:], overrides={'f_DDSM': f})
+
+
+# ---- the 26th output column: every member's snow depth at the end of the day (SIMPLYP_OUT_D_SNOW) -------------------------
+# The reference returns met_df['D_snow_end'] (inputs.py:197-207) as df_TC['D_snow'] (model.py:775-776); with the snow module
+# run per member inside the kernel the depth is a per-member series, so an ensemble that perturbs f_DDSM gets it back.
+
+def host_snow_depth(met, f_ddsm, d0):
+    """[D][E] D_snow_end of every member from the host snow function (bit-equal to the reference's column, tests/test_host.py)."""
+    return np.stack([sp.snow_hydrol_inputs(d, f, met[['T_air', 'PET', 'Precipitation']].copy())['D_snow_end'].to_numpy()
+                     for f, d in zip(f_ddsm, d0)], axis=1)
+
+
+def test_oracle_snow_depth_column_equals_host_snow_function(oracle_lib):
+    E = 5
+    m1, _ = setup('tarland_2004_dynamic', E, solver=dict(integrator='rk4', substeps=8), out_mask=marshal.mask_of_columns(['Qr', 'D_snow']))
+    out, st, _ = oracle_lib.run(m1['forcing'], m1['doy'], m1['member_params'], m1['reach_params'], m1['up_ptr'], m1['up_idx'], m1['opts'])
+    f_ddsm, d0 = snow_members(E)
+    assert out.shape[0] == 2 and np.array_equal(out[1, :, 0, :], host_snow_depth(m1['met'], f_ddsm, d0))
+    assert out[1].max() > 1.0                                   # there was snow
+    m1['opts'].snow = 0
+    with pytest.raises(ValueError, match='D_snow'):
+        oracle_lib.run(m1['forcing'][:, :2], m1['doy'], m1['member_params'], m1['reach_params'], m1['up_ptr'], m1['up_idx'], m1['opts'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,E,solver', [('tarland_2004_dynamic', 130, None),                       # quad kernel (auto), chain
+                                           ('tarland_2004_dynamic', 130, dict(lanes_per_member=1)),
+                                           ('tarland_1981_2010_dynamic', 300, dict(time_chunk_days=256, balance=1, out_slot_order=0)),   # queue: depth crosses chunks
+                                           ('confluence3_nc_2004', 70, None)])                         # every reach reports its member's depth
+def test_kernel_snow_depth_column(engine0, name, E, solver):
+    import torch
+    m1, _ = setup(name, E, solver=solver, out_mask=marshal.MASK_REACH5 | marshal.MASK_D_SNOW)
+    out, st, stats = engine0.run(m1['forcing'], m1['doy'], m1['member_params'], m1['reach_params'], m1['up_ptr'], m1['up_idx'], m1['opts'])
+    f_ddsm, d0 = snow_members(E)
+    want = host_snow_depth(m1['met'], f_ddsm, d0)
+    got = out[5].cpu().numpy()                                  # [D][n_reaches][E]
+    assert int(st.max()) == 0
+    for r in range(got.shape[1]):
+        assert np.array_equal(got[:, r, :], want)
+    # the other columns are what a run without the extra column writes
+    m1['opts'].out_mask = marshal.MASK_REACH5
+    ref, _, _ = engine0.run(m1['forcing'], m1['doy'], m1['member_params'], m1['reach_params'], m1['up_ptr'], m1['up_idx'], m1['opts'])
+    assert bool(torch.equal(out[:5], ref))
+
+
+@pytest.mark.gpu
+def test_snow_depth_column_needs_the_snow_module(engine0):
+    from simplyp_amd import engine
+    m0 = helpers.marshal_scenario('tarland_2004_dynamic', E=4, out_mask=marshal.MASK_REACH5 | marshal.MASK_D_SNOW)
+    with pytest.raises(engine.EngineError, match='opts.snow'):
+        engine0.run(m0['forcing'], m0['doy'], m0['member_params'], m0['reach_params'], m0['up_ptr'], m0['up_idx'], m0['opts'])
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('tarland_2004_dynamic')
+    f = np.array([2.74, 1.0, 5.0])
+    res = sp.run_simply_p_ensemble(met.copy(), p_struc, p_SU, p_LU, p_SC, p, dyn, overrides={'f_DDSM': f}, outputs=['Qr', 'D_snow'])
+    assert res['columns'] == ['Qr', 'D_snow']
+    assert np.array_equal(res['data'][1, :, 0, :], host_snow_depth(met, f, np.full(3, float(p['D_snow_0']))))
+    assert np.array_equal(res['data'][1, :, 0, 0], met['D_snow_end'].to_numpy())       # member 0 = the workbook = the reference's column
+    with pytest.raises(ValueError, match='snow_in_kernel'):
+        sp.run_simply_p_ensemble(met.copy(), p_struc, p_SU, p_LU, p_SC, p, dyn, n_members=2, outputs=['Qr', 'D_snow'])
