@@ -162,6 +162,39 @@ static const double CK_B[6] = {37.0 / 378, 0, 250.0 / 621, 125.0 / 594, 0, 512.0
 static const double CK_E[6] = {37.0 / 378 - 2825.0 / 27648, 0, 250.0 / 621 - 18575.0 / 48384,
                                125.0 / 594 - 13525.0 / 55296, -277.0 / 14336, 512.0 / 1771 - 1.0 / 4};   /* b - bhat */
 
+/* An explicit embedded Runge-Kutta pair as data: what cashkarp_aug_day's driver (erk_aug_day) steps with.  Cash-Karp is the one
+ * the device kernels implement; Tsitouras 5(4) exists here for the round-3 probe only (tools/probe_pair.py: would another pair
+ * need fewer right-hand sides under the same knee-aware controller?  oracle-only integrator id ORACLE_INTEG_TSIT5_AUG). */
+#define ERK_MAX_STAGES 7
+typedef struct {
+    int ns;                          /* stages */
+    int fsal;                        /* 1: the last stage is the derivative at the new point (b == last row of A) */
+    double A[ERK_MAX_STAGES][ERK_MAX_STAGES - 1];
+    double B[ERK_MAX_STAGES], E[ERK_MAX_STAGES];      /* weights of the higher-order solution; b - bhat */
+} erk_tableau;
+
+static const erk_tableau TAB_CASHKARP = {
+    6, 0,
+    {{0}, {1.0 / 5}, {3.0 / 40, 9.0 / 40}, {3.0 / 10, -9.0 / 10, 6.0 / 5}, {-11.0 / 54, 5.0 / 2, -70.0 / 27, 35.0 / 27},
+     {1631.0 / 55296, 175.0 / 512, 575.0 / 13824, 44275.0 / 110592, 253.0 / 4096}},
+    {37.0 / 378, 0, 250.0 / 621, 125.0 / 594, 0, 512.0 / 1771},
+    {37.0 / 378 - 2825.0 / 27648, 0, 250.0 / 621 - 18575.0 / 48384, 125.0 / 594 - 13525.0 / 55296, -277.0 / 14336, 512.0 / 1771 - 1.0 / 4}};
+
+/* Ch. Tsitouras, "Runge-Kutta pairs of order 5(4) satisfying only the first column simplifying assumption", Computers &
+ * Mathematics with Applications 62 (2011) 770-775.  7 stages, FSAL: 6 new right-hand sides per step.  (The 17 order
+ * conditions of order 5 hold for B to 1e-15 and those of order 4 for B - E: checked when the table was typed in.) */
+static const erk_tableau TAB_TSIT5 = {
+    7, 1,
+    {{0}, {0.161}, {-0.008480655492356989, 0.335480655492357},
+     {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
+     {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
+     {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383},
+     {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774, 0.0},
+    {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629, 0.5823571654525552,
+     -0.45808210592918697, 0.015151515151515152}};
+#define ORACLE_INTEG_TSIT5_AUG 12      /* not in include/simplyp.h: a probe of this file only */
+
 static int state_finite(const double* y)
 {   /* the 8 carried states (slots 0-4, 6, 8, 10) */
     static const int idx[8] = {0, 1, 2, 3, 4, 6, 8, 10};
@@ -313,10 +346,12 @@ static void ode_aug(const double* z, const ode_params* p, double invKv, double* 
 
 /* Same step-size rule as cashkarp_day (the kernel mirrors both).  y is the reference's 12-vector; slot 3
  * (Vr) is returned on its invariant. */
-static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rtol, double atol,
-                             int max_steps, double* h_carry, integ_stats* st)
+static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, double T, double rtol, double atol,
+                        int max_steps, double* h_carry, integ_stats* st)
 {
-    double k[6][NZ], zt[NZ], zn[NZ], z[NZ];
+    double k[ERK_MAX_STAGES][NZ], zt[NZ], zn[NZ], z[NZ];
+    const int ns = tab->ns;
+    int have_k0 = 0;                 /* FSAL pairs: k[0] already holds the derivative at the current point */
     /* (the step size carried over the day boundary belongs to the smooth end of a day; the forcing jumps at midnight and the first
      * attempt of the new day with it was rejected on 85 % of the member-days: SysAug::DAY_START of it is the better guess) */
     double t = 0.0, h = *h_carry * AUG_DAY_START;
@@ -333,7 +368,7 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
         if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
         int last_chance = (attempts + 1 >= max_steps);
         if (last_chance) hh = rem;
-        ode_aug(z, p, invKv, k[0]);
+        if (!have_k0) { ode_aug(z, p, invKv, k[0]); st->rhs += 1; }
         /* Aim at the knee (SysAug::KNEE_*): time to the nearest knee of a gate along the first slope; a knee inside the step
          * ends the step just past it, so that the right-hand side is smooth over all but its last few percent. */
         int targeted = 0, kink = 0, kink_gw = 0;
@@ -361,19 +396,19 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
             kink = hs < look;
             kink_gw = (hg < look) | (kink & (ugd > 0.0));
         }
-        for (int s = 1; s < 6; ++s) {
+        for (int s = 1; s < ns; ++s) {
             for (int i = 0; i < NZ; ++i) {
                 double acc = 0.0;
-                for (int j = 0; j < s; ++j) acc += CK_A[s][j] * k[j][i];
+                for (int j = 0; j < s; ++j) acc += tab->A[s][j] * k[j][i];
                 zt[i] = z[i] + hh * acc;
             }
             ode_aug(zt, p, invKv, k[s]);
         }
-        st->rhs += 6;
+        st->rhs += (uint64_t)(ns - 1);
         double err = 0.0; int bad = 0;
         for (int i = 0; i < NZ; ++i) {
             double inc = 0.0, ee = 0.0;
-            for (int s = 0; s < 6; ++s) { inc += CK_B[s] * k[s][i]; ee += CK_E[s] * k[s][i]; }
+            for (int s = 0; s < ns; ++s) { inc += tab->B[s] * k[s][i]; ee += tab->E[s] * k[s][i]; }
             zn[i] = z[i] + hh * inc;
             /* error norm: the 7 physical states (see below), and Qr**k_M (z[10]) at AUG_AUX_WEIGHT x the tolerance: on a day
              * when a nearly dry reach is wetted it grows 200-fold, and its own truncation error then showed in the sediment
@@ -408,14 +443,17 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
             memcpy(z, zn, sizeof(zn));
             t = (hh == rem) ? T : t + hh;
             st->steps++;
+            /* first same as last: the last stage was evaluated at the new point */
+            if (tab->fsal) { memcpy(k[0], k[ns - 1], sizeof(k[0])); have_k0 = 1; }
         } else {
-            st->rejected++;
+            st->rejected++;              /* (k[0] stays valid: same point) */
+            if (tab->fsal) have_k0 = 1;
         }
         /* pb, pk ride a neutrally stable manifold (nothing damps their drift from Qr**b, Qr**k) and are not in the error
          * norm, so on a storm day of 100+ steps the local errors would add up: re-evaluate them after every AUG_RESYNC-th
          * attempt of the day, accepted or not (a member's attempts are its own history; in the kernel the lanes of a
          * wavefront attempt in lockstep, so this test is wave-uniform there) */
-        if (attempts % AUG_RESYNC == 0 && t < T) { z[9] = pow(z[3], p->b_Q); z[10] = pow(z[3], p->k_M); }
+        if (attempts % AUG_RESYNC == 0 && t < T) { z[9] = pow(z[3], p->b_Q); z[10] = pow(z[3], p->k_M); have_k0 = 0; }
         double fac;
         if (bad) fac = SIMPLYP_CTRL_FAC_MIN;
         else if (err == 0.0) fac = SIMPLYP_CTRL_FAC_MAX;
@@ -427,6 +465,12 @@ static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rt
     y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[6] = z[4]; y[8] = z[5]; y[10] = z[6];
     y[5] = z[11]; y[7] = z[12]; y[9] = z[13]; y[11] = z[14];
     y[3] = Kv * pow(y[4], 1.0 - p->b_Q);
+}
+
+static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rtol, double atol,
+                             int max_steps, double* h_carry, integ_stats* st)
+{
+    erk_aug_day(&TAB_CASHKARP, y, p, T, rtol, atol, max_steps, h_carry, st);
 }
 
 /* ------------------------------------------------------------------------------------- */
@@ -779,8 +823,10 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
                 cashkarp_aug_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else if (n_integ == SIMPLYP_INTEG_CASHKARP_AUG_F32)
                 cashkarp_aug_f32_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
+            else if (n_integ == ORACLE_INTEG_TSIT5_AUG)
+                erk_aug_day(&TAB_TSIT5, y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else cashkarp_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
-            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG && n_integ != SIMPLYP_INTEG_CASHKARP_AUG_F32) {
+            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG && n_integ != SIMPLYP_INTEG_CASHKARP_AUG_F32 && n_integ != ORACLE_INTEG_TSIT5_AUG) {
                 /* Drift control (not in the reference).  The reference's own equations (:127-131) imply
                  * dVr = dQr * (1-b_Q) L / (a_Q 86400 Qr^b_Q), and Vr0 (:457-459) starts on that curve, so
                  * Vr == L Qr^(1-b_Q) / (a_Q 86400) for all t; Vr has no restoring term and a one-step

@@ -73,50 +73,48 @@ struct KernelArgs {
 // fp64 elementary functions on the VALU, trimmed to what this kernel needs: finite,
 // in-range arguments (no inf/nan/denormal branches), ~1 ulp.
 
-// exp(x) for |x| < 700.  n = rint(x/ln2), r = x - n ln2 (two-word ln2), degree-13 Taylor on
-// |r| <= 0.3466 (remainder < 4e-18), scale by 2^n.
-__device__ __forceinline__ double sp_exp(double x)
+// exp(x) for |x| < 700, N independent arguments evaluated in lockstep.  n = rint(x/ln2), r = x - n ln2 (two-word ln2),
+// degree-13 Taylor on |r| <= 0.3466 (remainder < 4e-18), scale by 2^n.  Every result is produced by the same operations in
+// the same order whatever N is and whichever slot it sits in, so exp values do not depend on how call sites group them (the
+// one-lane and the four-lane kernels group them differently and stay bit-identical).  Why group at all: the 14 polynomial
+// literals are 64-bit, i.e. two s_mov_b32 each, per call site and day -- and a lone wave pays a full issue slot for every
+// scalar instruction (tools/micro/valu_rates.hip).  The day boundary evaluates up to seven exponentials (exp(-mu VsA),
+// exp(-mu VsS), Qr**b_Q, Qr**k_M, Qr**(1-b_Q) and the two of discretized_soilP): one call site, one set of literals.
+template <int N>
+__device__ __forceinline__ void sp_expn(const double (&x)[N], double (&r)[N])
 {
-    const double n = __builtin_rint(x * 1.4426950408889634);
-    double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
-    r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;                    // 1/13!
-    p = __builtin_fma(p, r, 2.08767569878681e-09);        // 1/12!
-    p = __builtin_fma(p, r, 2.505210838544172e-08);       // 1/11!
-    p = __builtin_fma(p, r, 2.755731922398589e-07);       // 1/10!
-    p = __builtin_fma(p, r, 2.7557319223985893e-06);      // 1/9!
-    p = __builtin_fma(p, r, 2.48015873015873e-05);        // 1/8!
-    p = __builtin_fma(p, r, 1.984126984126984e-04);       // 1/7!
-    p = __builtin_fma(p, r, 1.388888888888889e-03);       // 1/6!
-    p = __builtin_fma(p, r, 8.333333333333333e-03);       // 1/5!
-    p = __builtin_fma(p, r, 4.1666666666666664e-02);      // 1/4!
-    p = __builtin_fma(p, r, 1.6666666666666666e-01);      // 1/3!
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_amdgcn_ldexp(p, (int)n);
+    double n[N], a[N], p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        n[i] = __builtin_rint(x[i] * 1.4426950408889634);
+        a[i] = __builtin_fma(n[i], -6.93147180369123816490e-01, x[i]);
+        a[i] = __builtin_fma(n[i], -1.90821492927058770002e-10, a[i]);
+        p[i] = 1.6059043836821613e-10;                          // 1/13!
+    }
+#define SP_STEP(c) _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = __builtin_fma(p[i], a[i], c);
+    SP_STEP(2.08767569878681e-09) SP_STEP(2.505210838544172e-08) SP_STEP(2.755731922398589e-07)       // 1/12! 1/11! 1/10!
+    SP_STEP(2.7557319223985893e-06) SP_STEP(2.48015873015873e-05) SP_STEP(1.984126984126984e-04)      // 1/9!  1/8!  1/7!
+    SP_STEP(1.388888888888889e-03) SP_STEP(8.333333333333333e-03) SP_STEP(4.1666666666666664e-02)     // 1/6!  1/5!  1/4!
+    SP_STEP(1.6666666666666666e-01) SP_STEP(0.5) SP_STEP(1.0) SP_STEP(1.0)                            // 1/3!  1/2!  1  1
+#undef SP_STEP
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_amdgcn_ldexp(p[i], (int)n[i]);
 }
 
-// Two independent exponentials evaluated in lockstep.  One wave per SIMD is resident (the Cash-Karp
-// stages need ~450 registers), so nothing hides the latency of a dependent fp64 FMA chain except
-// independent work in the same wave: interleaving the two Horner chains does that.
+__device__ __forceinline__ double sp_exp(double x)
+{
+    const double xs[1] = {x};
+    double rs[1];
+    sp_expn<1>(xs, rs);
+    return rs[0];
+}
+
 __device__ __forceinline__ void sp_exp2(double x0, double x1, double& r0, double& r1)
 {
-    const double n0 = __builtin_rint(x0 * 1.4426950408889634);
-    const double n1 = __builtin_rint(x1 * 1.4426950408889634);
-    double a = __builtin_fma(n0, -6.93147180369123816490e-01, x0);
-    double b = __builtin_fma(n1, -6.93147180369123816490e-01, x1);
-    a = __builtin_fma(n0, -1.90821492927058770002e-10, a);
-    b = __builtin_fma(n1, -1.90821492927058770002e-10, b);
-    double p = 1.6059043836821613e-10, q = 1.6059043836821613e-10;
-#define SP_STEP(c) p = __builtin_fma(p, a, c); q = __builtin_fma(q, b, c);
-    SP_STEP(2.08767569878681e-09) SP_STEP(2.505210838544172e-08) SP_STEP(2.755731922398589e-07)
-    SP_STEP(2.7557319223985893e-06) SP_STEP(2.48015873015873e-05) SP_STEP(1.984126984126984e-04)
-    SP_STEP(1.388888888888889e-03) SP_STEP(8.333333333333333e-03) SP_STEP(4.1666666666666664e-02)
-    SP_STEP(1.6666666666666666e-01) SP_STEP(0.5) SP_STEP(1.0) SP_STEP(1.0)
-#undef SP_STEP
-    r0 = __builtin_amdgcn_ldexp(p, (int)n0);
-    r1 = __builtin_amdgcn_ldexp(q, (int)n1);
+    const double xs[2] = {x0, x1};
+    double rs[2];
+    sp_expn<2>(xs, rs);
+    r0 = rs[0]; r1 = rs[1];
 }
 
 // 1/x: hardware seed + two Newton steps (full double precision for normal x).
@@ -892,8 +890,10 @@ __device__ __forceinline__ void quad_rhs(const double (&x)[3], const QuadConst& 
     qv = __builtin_fma(k.mP, x[0], o);
 }
 
-// ck_day<SysAug> for a quad.  z[11] / yq[4] hold the member's whole state on every lane of the quad, on entry and on return.
-__device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], const DayConst& c,
+// ck_day<SysAug> for a quad.  z[7] (the physical states VsA VsS Vg Qr Msus TDPr PPr) and yq[4] hold the member's state on every
+// lane of the quad, on entry and on return; aux1 is THIS lane's carried function for the day's start (lane 0: exp(-mu VsA),
+// 1: exp(-mu VsS), 2: Qr**k_M, 3: cQ Qr**b_Q -- evaluated by run_slot at the day boundary, one exponential per lane).
+__device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, double (&yq)[4], const DayConst& c,
                                             const double T, const double rtol, const double atol, int max_steps, double& h_carry,
                                             CkCounters& cnt, const bool lane_active, const int j)
 {
@@ -925,7 +925,14 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
     bool gave_up_today = false;
     bool alive = true;
 #pragma unroll
-    for (int i = 0; i < 11; ++i) alive = alive && (sp_abs(z[i]) < sp_huge<R>());
+    for (int i = 0; i < 7; ++i) alive = alive && (sp_abs(z[i]) < sp_huge<R>());
+    {
+        // ... and the four carried functions, one per lane: a member whose state is already non-finite is not integrated further
+        int dead = (sp_abs(aux1) < sp_huge<R>()) ? 0 : 1;
+        dead |= __builtin_amdgcn_update_dpp(0, dead, SP_QP(1, 0, 3, 2), 0xf, 0xf, true);
+        dead |= __builtin_amdgcn_update_dpp(0, dead, SP_QP(2, 3, 0, 1), 0xf, 0xf, true);
+        alive = alive && (dead == 0);
+    }
     if (!alive) {
         cnt.poisoned = true;
 #pragma unroll
@@ -936,7 +943,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
     // this lane's slots of the member's state, and its daily integral
     R y[3];
     y[0] = sel4(j, z[0], z[1], z[2], z[3]);
-    y[1] = sel4(j, z[7], z[8], z[10], z[9]);
+    y[1] = aux1;
     y[2] = sel4(j, z[4], z[5], z[6], 0.0);
     double yqv = sel4(j, yq[1], yq[2], yq[3], yq[0]);
 
@@ -1109,7 +1116,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[11], double (&yq)[4], co
     cnt.rejected += n_alive - n_acc - (gave_up_today ? 1u : 0u);
     h_carry = (double)h;
 
-    // the member's state back on every lane of the quad (the carried functions z[7..10] are re-evaluated at the next day start)
+    // the member's state back on every lane of the quad (the carried functions are re-evaluated at the day boundary)
     z[0] = quad_bcast<0>(y[0]); z[1] = quad_bcast<1>(y[0]); z[2] = quad_bcast<2>(y[0]); z[3] = quad_bcast<3>(y[0]);
     z[4] = quad_bcast<0>(y[2]); z[5] = quad_bcast<1>(y[2]); z[6] = quad_bcast<2>(y[2]);
     yq[0] = quad_bcast<3>(yqv); yq[1] = quad_bcast<0>(yqv); yq[2] = quad_bcast<1>(yqv); yq[3] = quad_bcast<2>(yqv);
@@ -1123,21 +1130,40 @@ __device__ __forceinline__ int nc_type_of(double f_NC_A, double f_NC_S)     // m
     return f_NC_A > 0.0 ? 1 : (f_NC_S > 0.0 ? 2 : 0);
 }
 
-// discretized_soilP (model.py:39-56) followed by the >= 0 clamps (:696-699)
-__device__ __forceinline__ void soil_p_update(double P_netInput, double A_catch, double KfMsoil, double EPC0,
-                                              double Qs, double Qq, double Vs, double& TDPs, double& Plab)
+// discretized_soilP (model.py:39-56) followed by the >= 0 clamps (:696-699) and the soil-water concentration (:702-703), in two
+// phases around the day boundary's one group of exponentials (sp_expn): soil_p_rate gives b (:43), whose exp(-b) the caller
+// evaluates together with the day's other exponentials; soil_p_update does the rest.  The reference's nine divisions per call
+// (by b, by Vs, by b*Vs) share two reciprocals, 1/Vs and 1/b (sp_rcp: hardware seed + two Newton steps, correctly rounded on
+// every sample tried, tools/micro/rcp_accuracy.hip): a * (1/b) instead of a / b differs in the last bit at most -- eleven orders
+// of magnitude below the parity bar -- and an IEEE division is ~12 instructions on this chip, a quarter of the day-boundary
+// code before round 3.  (Vs == 0 never happens with water in the soil box; the reference leaves NaN in conc_TDPs there, here
+// the reciprocal does, and the member is flagged.)
+struct SoilPRate { double rVs, b; };
+
+__device__ __forceinline__ SoilPRate soil_p_rate(double KfMsoil, double Qs, double Qq, double Vs)
 {
-    const double a = P_netInput * A_catch * 100.0 / 365. + KfMsoil * EPC0;        // :42
-    const double b = (KfMsoil + Qs + Qq) / Vs;                                    // :43
-    const double aob = a / b;
-    const double emb = sp_exp(__builtin_fmax(-b, -700.0));
+    SoilPRate r;
+    r.rVs = sp_rcp(Vs);
+    r.b = (KfMsoil + Qs + Qq) * r.rVs;                                            // :43
+    return r;
+}
+
+// aP = P_netInput * A_catch * 100 / 365 (:42, constant over the run); emb = exp(max(-b, -700))
+__device__ __forceinline__ void soil_p_update(double aP, double KfMsoil, double EPC0, double Vs, const SoilPRate& r, double emb,
+                                              double& TDPs, double& Plab, double& conc)
+{
+    const double a = aP + KfMsoil * EPC0;                                         // :42
+    const double rb = sp_rcp(r.b);
+    const double aob = a * rb;
     double T = aob + (TDPs - aob) * emb;                                          // :44
     double sorp = 0.0;
+    const double aobv = aob * r.rVs;                                              // a / (b Vs) = a / b0, :47
     if (Vs > 0.0)                                                                 // :50
-        sorp = KfMsoil * (a / (b * Vs) - EPC0 + (1.0 / b) * (T / Vs - a / (b * Vs)) * (1.0 - emb));   // :51
+        sorp = KfMsoil * (aobv - EPC0 + (rb * (T * r.rVs - aobv)) * (1.0 - emb));     // :51
     double Pl = Plab + sorp;                                                      // :54
     TDPs = (0.0 > T) ? 0.0 : T;                                                   // :696 (NaN stays NaN, like Python max)
     Plab = (0.0 > Pl) ? 0.0 : Pl;                                                 // :697
+    conc = TDPs * r.rVs;                                                          // :702-703
 }
 
 // Everything one lane does for one member over days [d_begin, d_end) of every reach of its chain.
@@ -1265,14 +1291,47 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
         const double dmid0 = MPv(SIMPLYP_PM_D_MAXE_SPR), dmid1 = MPv(SIMPLYP_PM_D_MAXE_AUT);
         const double C_out = C_cover_A0 - (60.0 * (1 - C_cover_A0) / (2 * (365 - 60.0)));         // :575-576
         const double E_PP = MPv(SIMPLYP_PM_E_PP);
-        const double PnetA = MPv(SIMPLYP_PM_P_NETINPUT_A), PnetNC = MPv(SIMPLYP_PM_P_NETINPUT_NC);
         const double wA = f_A * (1 - f_NC_A);                 // TDP source weights (:155-161)
         const double wNC = f_A * f_NC_A + f_S * f_NC_S;
+        // Divisions by run constants become multiplications by their reciprocals, formed once per reach (IEEE divisions here);
+        // an IEEE fp64 division is ~12 instructions and the day boundary had 22 of them (a quarter of its issue slots).
+        const double aP_A = MPv(SIMPLYP_PM_P_NETINPUT_A) * A_catch * 100.0 / 365.;                // :42, first term
+        const double aP_NC = MPv(SIMPLYP_PM_P_NETINPUT_NC) * A_catch * 100.0 / 365.;
+        const double invKfMsoil = 1.0 / KfMsoil, invMsoil = 1.0 / Msoil;
+        const double p0 = P_inactive * invMsoil;
 
         const int up_lo = a.up_ptr[s], up_hi = a.up_ptr[s + 1];
         const int rslot = a.route_slot[s];
         const int oslot = a.out_slot[s];
         double* route_w = rslot >= 0 ? a.route + (size_t)rslot * 4 * RD * E : nullptr;
+        // output rows: row r of column k of this member sits at o_member + (k n_rows + r) row_stride
+        const bool reduce = a.n_periods > 0;
+        const size_t row_stride = (size_t)a.n_out_reaches * E;
+        const size_t col_stride = (size_t)(reduce ? a.n_periods : D) * row_stride;
+        double* const o_member = a.out + (size_t)(oslot >= 0 ? oslot : 0) * E + (a.out_by_slot ? slot : e);
+        double* o_day = o_member + (size_t)d_begin * row_stride;       // daily rows: advanced by one row per day
+
+        // Scheme 2 (and its fp32-stage variant): the auxiliary states for the day's start -- exp(-mu VsA), exp(-mu VsS), Qr**b_Q
+        // (x cQ in the fp64 scheme: SysAug::f), Qr**k_M -- are exact functions of the carried state.  They are evaluated at the END
+        // of the previous day, in one group with that day's other exponentials (below), and before the first day here; same
+        // operations on the same inputs either way, so a run cut into time chunks reproduces them bit for bit.
+        // TEAM == 4: a lane carries only its own slot-1 value (lane 0: EA, 1: ES, 2: pk, 3: cQ pb).
+        constexpr bool HAS_AUX = (INTEG == SIMPLYP_INTEG_CASHKARP_AUG || INTEG == SIMPLYP_INTEG_CASHKARP_AUG_F32);
+        constexpr bool AUX_CQ = (INTEG == SIMPLYP_INTEG_CASHKARP_AUG);
+        const int qj = lane & 3;
+        double aux[4] = {0.0, 0.0, 0.0, 0.0};                 // TEAM == 4: aux[0] only
+        double lq = 0.0;                                      // log Qr of the carried state
+        if (HAS_AUX) {
+            lq = sp_log(y[4]);
+            if (TEAM == 4) {
+                aux[0] = sp_exp(sel4(qj, -mu * y[0], -mu * y[1], k_M * lq, b_Q * lq)) * (qj == 3 ? c.cQ : 1.0);
+            } else {
+                const double xs[4] = {-mu * y[0], -mu * y[1], b_Q * lq, k_M * lq};
+                double rs[4];
+                sp_expn<4>(xs, rs);
+                aux[0] = rs[0]; aux[1] = rs[1]; aux[2] = AUX_CQ ? rs[2] * c.cQ : rs[2]; aux[3] = rs[3];
+            }
+        }
 
         for (int d0 = d_begin; d0 < d_end; d0 += TILE_D) {
             const int nd = min(TILE_D, d_end - d0);
@@ -1337,8 +1396,8 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
 
                 double EPC0_A, EPC0_NC;
                 if (a.dynamic_epc0) {
-                    EPC0_A = __builtin_fmax(Plab_A / KfMsoil, 0.0);                               // :602
-                    EPC0_NC = __builtin_fmax(Plab_NC / KfMsoil, 0.0);                             // :603
+                    EPC0_A = __builtin_fmax(Plab_A * invKfMsoil, 0.0);                            // :602
+                    EPC0_NC = __builtin_fmax(Plab_NC * invKfMsoil, 0.0);                          // :603
                 } else {
                     EPC0_A = EPC0_0_A;                                                            // :607
                     EPC0_NC = (nc_type == 2) ? EPC0_0_A : EPC0_0_S;                               // :608-611
@@ -1358,8 +1417,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     c.tconst = Qq * (wA * conc_A + wNC * conc_NC) + TDPeff + TDPrUS;      // :159-165
                 }
                 {
-                    const double pA = (Plab_A + P_inactive) / Msoil, pN = (Plab_NC + P_inactive) / Msoil;
-                    const double p0 = P_inactive / Msoil;
+                    const double pA = (Plab_A + P_inactive) * invMsoil, pN = (Plab_NC + P_inactive) * invMsoil;
                     c.cPP = E_PP * (f_Ar * Esus_A * ((1 - f_NC_Ar) * pA + f_NC_Ar * pN)
                                     + f_IG * Esus_IG * ((1 - f_NC_IG) * pA + f_NC_IG * pN)
                                     + f_S * Esus_S * ((1 - f_NC_S) * p0 + f_NC_S * pN));           // :171-176
@@ -1371,24 +1429,18 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                 if (INTEG == SIMPLYP_INTEG_RK4) {
                     rk4_day(y, yq, c, a.step_len, a.substeps);
                     n_rhs += 4u * (unsigned)a.substeps; n_steps += (unsigned)a.substeps;
-                    if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));    // Vr = Kv Qr^(1-b_Q), see oracle
                 } else if (INTEG == SIMPLYP_INTEG_CASHKARP) {
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
                     ck_day<SysLiteral>(y, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
-                    if (a.project_vr) y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));
                 } else if (INTEG == SIMPLYP_INTEG_CASHKARP_AUG_F32) {
-                    // fp32 stages: carried state and day constants are rounded to float for the day's integration
+                    // fp32 stages: carried state, auxiliary states and day constants are rounded to float for the day's integration
                     float z[11];
                     z[0] = (float)y[0]; z[1] = (float)y[1]; z[2] = (float)y[2]; z[3] = (float)y[4];
                     z[4] = (float)y[5]; z[5] = (float)y[6]; z[6] = (float)y[7];
-                    double ea, es, pb0, pk0;
-                    sp_exp2(-mu * y[0], -mu * y[1], ea, es);
-                    const double lq0 = sp_log(y[4]);
-                    sp_exp2(b_Q * lq0, k_M * lq0, pb0, pk0);
-                    z[7] = (float)ea; z[8] = (float)es; z[9] = (float)pb0; z[10] = (float)pk0;
+                    z[7] = (float)aux[0]; z[8] = (float)aux[1]; z[9] = (float)aux[2]; z[10] = (float)aux[3];
                     const DayConstF cf(c);
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
                     ck_day<SysAugF>(z, yq, cf, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
@@ -1396,48 +1448,82 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
                     y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
-                    y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));                  // Vr on its invariant
                 } else {
-                    // augmented form: the auxiliary states are re-evaluated exactly from VsA, VsS, Qr every day
-                    double z[11];
-                    z[0] = y[0]; z[1] = y[1]; z[2] = y[2]; z[3] = y[4]; z[4] = y[5]; z[5] = y[6]; z[6] = y[7];
-                    sp_exp2(-mu * y[0], -mu * y[1], z[7], z[8]);
-                    const double lq0 = sp_log(y[4]);
-                    sp_exp2(b_Q * lq0, k_M * lq0, z[9], z[10]);
-                    z[9] *= c.cQ;                                        // the state carried is cQ Qr**b_Q (SysAug::f)
+                    // augmented form
                     CkCounters cnt = {0u, 0u, 0u, 0u, false, false};
-                    if (TEAM == 4) ck_day_quad(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active, lane & 3);
-                    else ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
+                    if (TEAM == 4) {
+                        double z[7];
+                        z[0] = y[0]; z[1] = y[1]; z[2] = y[2]; z[3] = y[4]; z[4] = y[5]; z[5] = y[6]; z[6] = y[7];
+                        ck_day_quad(z, aux[0], yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active, qj);
+                        y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
+                    } else {
+                        double z[11];
+                        z[0] = y[0]; z[1] = y[1]; z[2] = y[2]; z[3] = y[4]; z[4] = y[5]; z[5] = y[6]; z[6] = y[7];
+                        z[7] = aux[0]; z[8] = aux[1]; z[9] = aux[2]; z[10] = aux[3];
+                        ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
+                        y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
+                    }
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
                     if (cnt.capped) stat |= SIMPLYP_STATUS_STEPCAP;
                     if (cnt.poisoned) stat |= SIMPLYP_STATUS_NONFINITE;
-                    y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
-                    y[3] = Kv * sp_exp((1.0 - b_Q) * sp_log(y[4]));                  // Vr on its invariant
-                }
-                {
-                    bool fin = true;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) fin = fin && (__builtin_fabs(y[i]) < 1.0e300);
-                    if (!fin) stat |= SIMPLYP_STATUS_NONFINITE;
                 }
                 const double Vg_ode = y[2];                                                       // stored 'Vg' (:644)
 
                 // ---- end-of-day explicit flows and resets (:663-670) ----
                 const double uA = y[0] - fc, uS = y[1] - fc;
-                const double QsA = uA * gate(uA, c.inv_d) / T_s_A;                                // :663
-                const double QsS = uS * gate(uS, c.inv_d) / T_s_S;                                // :664
-                const double ug = y[2] / T_g - Qg_min;
+                const double QsA = uA * gate(uA, c.inv_d) * c.invTsA;                             // :663
+                const double QsS = uS * gate(uS, c.inv_d) * c.invTsS;                             // :664
+                const double ug = __builtin_fma(y[2], c.invTg, -Qg_min);
                 const double Qg = Qg_min + gate(ug, c.inv_dg) * ug;                               // :668-669
                 y[2] = Qg * T_g;                                                                  // :670
 
-                // ---- soil P (:676-715) ----
-                const double VsNC = (nc_leak == 1) ? y[0] : y[1];
+                // ---- the day boundary's exponentials, one group (sp_expn) ----
+                //   Vr on its invariant: Kv Qr**(1-b_Q) (schemes 2, 3 always; 0, 1 with opts.project_vr: see the oracle);
+                //   exp(-b) of the two discretized_soilP calls (:44, :51);
+                //   schemes 2, 3: the auxiliary states of the next day's start.
+                const bool want_vr = HAS_AUX || a.project_vr;
+                if (want_vr) lq = sp_log(y[4]);
+                const double VsNC = (nc_leak == 1) ? y[0] : y[1];                                 // :676-681
                 const double QsNC = (nc_leak == 1) ? QsA : QsS;
+                SoilPRate rA = {0.0, 0.0}, rNC = {0.0, 0.0};
                 if (a.dynamic_epc0) {
-                    soil_p_update(PnetA, A_catch, KfMsoil, EPC0_A, QsA, Qq, y[0], TDPs_A, Plab_A);       // :688-689
-                    soil_p_update(PnetNC, A_catch, KfMsoil, EPC0_NC, QsNC, Qq, VsNC, TDPs_NC, Plab_NC);  // :692-693
-                    conc_A = TDPs_A / y[0];                                                       // :702
-                    conc_NC = TDPs_NC / VsNC;                                                     // :703
+                    rA = soil_p_rate(KfMsoil, QsA, Qq, y[0]);
+                    rNC = soil_p_rate(KfMsoil, QsNC, Qq, VsNC);
+                }
+                const double xA = __builtin_fmax(-rA.b, -700.0), xNC = __builtin_fmax(-rNC.b, -700.0);
+                const double xVr = (1.0 - b_Q) * lq;
+                double embA, embNC, eVr;
+                if (TEAM == 4) {
+                    const double xs[2] = {sel4(qj, -mu * y[0], -mu * y[1], k_M * lq, b_Q * lq), sel4(qj, xA, xNC, xVr, 0.0)};
+                    double rs[2];
+                    sp_expn<2>(xs, rs);
+                    aux[0] = rs[0] * (qj == 3 ? c.cQ : 1.0);
+                    embA = quad_bcast<0>(rs[1]); embNC = quad_bcast<1>(rs[1]); eVr = quad_bcast<2>(rs[1]);
+                } else if (HAS_AUX) {
+                    const double xs[7] = {-mu * y[0], -mu * y[1], b_Q * lq, k_M * lq, xVr, xA, xNC};
+                    double rs[7];
+                    sp_expn<7>(xs, rs);
+                    aux[0] = rs[0]; aux[1] = rs[1]; aux[2] = AUX_CQ ? rs[2] * c.cQ : rs[2]; aux[3] = rs[3];
+                    eVr = rs[4]; embA = rs[5]; embNC = rs[6];
+                } else {
+                    const double xs[3] = {xVr, xA, xNC};
+                    double rs[3];
+                    sp_expn<3>(xs, rs);
+                    eVr = rs[0]; embA = rs[1]; embNC = rs[2];
+                }
+                if (want_vr) y[3] = Kv * eVr;                                                     // Vr = Kv Qr**(1-b_Q)
+                {
+                    bool fin = true;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) fin = fin && (__builtin_fabs(y[i]) < 1.0e300);
+                    fin = fin && (__builtin_fabs(Vg_ode) < 1.0e300);
+                    if (!fin) stat |= SIMPLYP_STATUS_NONFINITE;
+                }
+
+                // ---- soil P (:676-715) ----
+                if (a.dynamic_epc0) {
+                    soil_p_update(aP_A, KfMsoil, EPC0_A, y[0], rA, embA, TDPs_A, Plab_A, conc_A);         // :688-689, :696-697, :702
+                    soil_p_update(aP_NC, KfMsoil, EPC0_NC, VsNC, rNC, embNC, TDPs_NC, Plab_NC, conc_NC);  // :692-693, :698-699, :703
                 } else {
                     conc_A = EPC0_A;                                                              // :711
                     conc_NC = EPC0_NC;                                                            // :715
@@ -1453,10 +1539,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                         // daily rows, or (time-reduced output) running sums over the day's period: the row is owned
                         // by this member, so the read-modify-write needs no atomics; consecutive days hit the same
                         // L2-resident line, and across time chunks the queue kernel's release/acquire covers it
-                        const bool reduce = a.n_periods > 0;
-                        const size_t row = reduce ? (size_t)a.period_of_day[d] : (size_t)d;
-                        const size_t col_stride = (size_t)(reduce ? a.n_periods : D) * a.n_out_reaches * E;
-                        double* o = a.out + (row * a.n_out_reaches + oslot) * E + (a.out_by_slot ? slot : e);
+                        double* o = reduce ? o_member + (size_t)a.period_of_day[d] * row_stride : o_day;
                         unsigned m = a.out_mask;
 #define PUT(col, val) if (m & (1u << (col))) { *o = reduce ? *o + (val) : (val); o += col_stride; }
                         PUT(SIMPLYP_OUT_VSA, y[0]) PUT(SIMPLYP_OUT_VSS, y[1]) PUT(SIMPLYP_OUT_VG, Vg_ode)
@@ -1472,6 +1555,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
 #undef PUT
                     }
                 }
+                o_day += row_stride;
             }
         }
         if (ckpt && d_end < D && writer) {      // hand the state to whichever wave runs the next time chunk
