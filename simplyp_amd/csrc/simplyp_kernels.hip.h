@@ -427,7 +427,7 @@ struct SysAug {
 
 
 // fp32 working precision for the augmented system (SIMPLYP_INTEG_CASHKARP_AUG_F32, BASELINE config C5): the 11 stage
-// states and all stage arithmetic in float (half the registers, twice the VALU rate once two waves share a SIMD);
+// states and all stage arithmetic in float (a lone wave issues v_fma_f32 twice as fast as v_fma_f64: 1.29 against 2.6 ns);
 // the four daily integrals are accumulated in fp64, and everything outside the day's integration -- the carried
 // state, labile soil P and soil-water TDP (whose daily increments are ~1e-4 of their size), the day constants --
 // stays fp64.
@@ -801,10 +801,13 @@ __device__ __forceinline__ double quad_perm(double v)
 template <int J> __device__ __forceinline__ double quad_bcast(double v) { return quad_perm<SP_QP(J, J, J, J)>(v); }
 
 struct QuadConst {
-    // gate of slot 0:  w = fma(x0, cw, w0);  s = clamp(fma(j == 2 ? w : x0, cs, s0c));  Q = fma(s s (3 - 2 s), w, q0)
-    double cw, w0, cs, s0c, q0;
-    // slot-0 derivative:  t = fma(cA, j < 2 ? x1 : Qsum, fma(nG, Qg, cB));  d0 = fma(nZ, x0, fma(nQ, Q, fma(mP, Qg, t))) * fma(mP, x1, m012)
-    double cA, cB, nG, mP, nQ, nZ, m012;
+    // gate of slot 0:  w = fma(x0, cw, w0);  s = clamp(fma(x0, csx, fma(w, csw, s0c)));  Q = fma(s s (3 - 2 s), w, q0)
+    // (soil lanes: csx = 1/(0.01 fc), csw = 0; groundwater lane: csx = 0, csw = 1/(0.01 Qg_min) -- the FMA with the zero
+    // coefficient returns its addend exactly, so each lane's s is the one-lane kernel's, and no select is needed)
+    double cw, w0, csx, csw, s0c, q0;
+    // slot-0 derivative:  t = fma(cA1, x1, fma(cA2, Qsum, fma(nG, Qg, cB)));  d0 = fma(nZ, x0, fma(nQ, Q, fma(mP, Qg, t))) * fma(mP, x1, m012)
+    // (soil lanes: cA1 = alpha PET, cA2 = 0; the others: cA1 = 0, cA2 = beta | 1 - beta)
+    double cA1, cA2, cB, nG, mP, nQ, nZ, m012;
     // slot-1 derivative:  d1 = (c1 x1) * rate
     double c1;
     // slot-2 derivative:  d2 = fma(mK, pk, fma(mA, QsA, fma(mS, QsS, fma(mG, Qg, m4)))) - x2 kap
@@ -832,10 +835,12 @@ __device__ __forceinline__ QuadConst quad_const(const DayConst& c, int j)
     QuadConst k;
     k.cw = sel4(j, c.invTsA, c.invTsS, c.invTg, 0.0);
     k.w0 = sel4(j, c.wA0, c.wS0, -c.Qgmin, 0.0);
-    k.cs = sel4(j, c.inv_d, c.inv_d, c.inv_dg, 0.0);
+    k.csx = sel4(j, c.inv_d, c.inv_d, 0.0, 0.0);
+    k.csw = sel4(j, 0.0, 0.0, c.inv_dg, 0.0);
     k.s0c = sel4(j, c.s0, c.s0, 0.0, 0.0);
     k.q0 = sel4(j, -0.0, -0.0, c.Qgmin, 0.0);       // fma(g, w, -0.0) == g * w, sign of zero included
-    k.cA = sel4(j, c.aE, c.aE, c.beta, c.omb);
+    k.cA1 = sel4(j, c.aE, c.aE, 0.0, 0.0);
+    k.cA2 = sel4(j, 0.0, 0.0, c.beta, c.omb);
     k.cB = sel4(j, c.c0m, c.c0m, 0.0, c.qin);
     k.nG = sel4(j, 0.0, 0.0, -1.0, 0.0);
     k.mP = sel4(j, 0.0, 0.0, 0.0, 1.0);
@@ -866,13 +871,13 @@ __device__ __forceinline__ void quad_rhs(const double (&x)[3], const QuadConst& 
 {
     // smooth-step gate of the store in slot 0: QsA, QsS (:105, :109), Qg (:121-122); lane 3 gets 0
     const double w = __builtin_fma(x[0], k.cw, k.w0);
-    double s = __builtin_fma(j_eq2 ? w : x[0], k.cs, k.s0c);
+    double s = __builtin_fma(x[0], k.csx, __builtin_fma(w, k.csw, k.s0c));
     s = __builtin_fmin(__builtin_fmax(s, 0.0), 1.0);
     const double Q = __builtin_fma((s * s) * __builtin_fma(-2.0, s, 3.0), w, k.q0);
     const double QsA = quad_bcast<0>(Q), QsS = quad_bcast<1>(Q), Qg = quad_bcast<2>(Q);
     const double Qsum = __builtin_fma(k.fA, QsA, k.fS * QsS);
     // slot 0: dVsA, dVsS (:106, :110), dVg (:124), dQr (:127-130)
-    const double t = __builtin_fma(k.cA, j_lt2 ? x[1] : Qsum, __builtin_fma(k.nG, Qg, k.cB));
+    const double t = __builtin_fma(k.cA1, x[1], __builtin_fma(k.cA2, Qsum, __builtin_fma(k.nG, Qg, k.cB)));
     const double u = __builtin_fma(k.mP, Qg, t);
     const double v = __builtin_fma(k.nZ, x[0], __builtin_fma(k.nQ, Q, u));
     d[0] = v * __builtin_fma(k.mP, x[1], k.m012);
@@ -965,12 +970,27 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
         sq = b1 * kq;
         bool targeted = false;
         R kfac = 1.0;
+        // Knee logic of ck_day<SysAug>, with a wave-uniform shortcut in front.  This lane's gate argument moves along the first
+        // slope as g(t) = g + sl t; it has a knee (g = 0 or g = gd) at a time in (a, b) exactly when g(a) and g(b), or g(a) - gd
+        // and g(b) - gd, differ in sign -- four FMAs and two sign tests, no reciprocal.  With (a, b) = (0.9 KNEE_LO hh,
+        // 1.1 KINK_REACH hh), a window 10 % wider on both sides than everything the logic below looks at (its times carry the
+        // 5e-8 of the hardware reciprocal), "no lane of the wave sees a knee in the window" implies that the full logic would
+        // leave the step alone (no targeting, factor 1): skipping it then changes nothing, bit for bit.  The waves this kernel
+        // exists for carry 1 to 16 members and most of their attempts are far from every knee (a 64-member wave of the one-lane
+        // kernel nearly always has some lane near one: no shortcut there).
+        const R g = sp_fma(y[0] - k.eoff, k.gs, k.g0), sl = k1[0] * k.gs;
+        const R gdg = k.gd - g;
+        bool near_knee;
         {
+            const R ta = (0.9 * SysAug::KNEE_LO) * hh, tb = (1.1 * SysAug::KINK_REACH) * hh;
+            const R e0 = sp_fma(sl, ta, g), e1 = sp_fma(sl, tb, g);
+            const R f0 = sp_fma(sl, ta, -gdg), f1 = sp_fma(sl, tb, -gdg);
+            near_knee = (sp_sign_xor(e0, e1) | sp_sign_xor(f0, f1)) < 0;
+        }
+        if (__any(near_knee)) {
             // times to the knees along the first slope, as in ck_day<SysAug>: this lane's gate, then the quad's minimum
             const R tlo = SysAug::KNEE_LO * hh;
-            const R g = sp_fma(y[0] - k.eoff, k.gs, k.g0), sl = k1[0] * k.gs;
             const R r = sp_rcp_fast(sl);
-            const R gdg = k.gd - g;
             const R t0 = (0.0 - g) * r, t1 = gdg * r;
             const R tn = sp_min_raw(sp_if_above(t0, tlo), sp_if_above(t1, tlo));
             R hk = sp_min_raw(huge, tn);
@@ -1593,7 +1613,12 @@ __device__ __forceinline__ int slot_of_lane(const KernelArgs& a, int group, int 
     return l < a.lanes ? group * a.lanes + l : a.E;
 }
 
-// fp64 schemes need ~500 registers for the Cash-Karp stages (one wave per SIMD); the fp32 scheme is asked to fit two
+// One wave per SIMD for every instantiation (__launch_bounds__(64, 1)): the fp64 schemes need ~450-500 registers for the
+// Cash-Karp stages, and the fp32-stage scheme gains nothing from a second wave -- the chip issues v_fma_f32 every 1.29 ns for a
+// lone wave and every 2.15 ns per wave with a partner on the SIMD, i.e. co-residency is worth 1.20 x on a bare FMA stream
+// (tools/micro/valu_rates.hip, profiles/r02_valu_rates.log), while fitting two waves (256 registers each, with the fp64 day-level
+// state beside the float stages) spilled 712 B per lane to scratch and ran 22 % slower (profiles/r02_experiments.md).  What
+// makes BASELINE config C5 fast is its tolerance (44 instead of 84 right-hand sides per catchment-day), not the fp32 rate.
 template <int INTEG, bool SNOW, int TEAM>
 __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs a)
 {
