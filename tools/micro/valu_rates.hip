@@ -6,7 +6,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-enum { FMA64_DEP1, FMA64_DEP2, FMA64_DEP4, FMA64, MUL64, ADD64, MAX64, MIN64, RCP64, CMPSEL64, CVT6432, FMA32, PKFMA32, RCP32, EXP32, LOG32, FMA64_SMOV2, FMA64_SNOP, N_OPS };
+enum { FMA64_DEP1, FMA64_DEP2, FMA64_DEP4, FMA64, MUL64, ADD64, MAX64, MIN64, RCP64, CMPSEL64, CVT6432, FMA32, PKFMA32, RCP32, EXP32, LOG32, FMA64_SMOV2, FMA64_SNOP, DPP32X2, DPP64, DPP64_FMA, CNDMASK2, N_OPS };
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 template <int OP>
@@ -42,6 +42,14 @@ __global__ __launch_bounds__(64, 1) void k(double* out, long long* cyc, int iter
                 if (OP == FMA64_SMOV2) { a[i] = __builtin_fma(a[i], c1, c2); asm volatile("s_mov_b32 s40, 0x1234\n\ts_mov_b32 s41, 0x5678" ::: "s40", "s41"); }
                 if (OP == FMA64_SNOP) { a[i] = __builtin_fma(a[i], c1, c2); asm volatile("s_nop 0"); }
                 if (OP == CVT6432) a[i] += 1.0;                                              // keeps the conversions distinct: + v_add_f64
+                // a double handed to the other lanes of a quad: two 32-bit DPP moves (quad_perm) ...
+                if (OP == DPP32X2) asm volatile("v_mov_b32_dpp %0, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                                "v_mov_b32_dpp %1, %3 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                                                : "=v"(f[i]), "=v"(f[(i + 1) & 15]) : "v"(f[(i + 2) & 15]), "v"(f[(i + 3) & 15]));
+                // ... or one 64-bit DPP move (gfx90a+: row_newbcast only -- a lane of each row of 16 to the whole row)
+                if (OP == DPP64) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(a[i]) : "v"(a[(i + 1) & 15]));
+                if (OP == DPP64_FMA) { asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(a[i]) : "v"(a[(i + 1) & 15])); a[(i + 5) & 15] = __builtin_fma(a[(i + 5) & 15], c1, a[i]); }
+                if (OP == CNDMASK2) a[i] = (threadIdx.x & 1) ? a[i] : a[(i + 1) & 15];          // 2 v_cndmask_b32 on a lane-constant condition
             }
     }
     const long long t1 = clock64();
@@ -104,5 +112,9 @@ int main()
     run<LOG32>("v_log_f32", out, cyc, 0);
     run<FMA64_SMOV2>("v_fma_f64 + 2 s_mov_b32", out, cyc, 0);
     run<FMA64_SNOP>("v_fma_f64 + s_nop 0", out, cyc, 0);
+    run<DPP32X2>("2 v_mov_b32_dpp quad_perm (a double)", out, cyc, 0);
+    run<DPP64>("v_mov_b64_dpp row_newbcast (a double)", out, cyc, 0);
+    run<DPP64_FMA>("v_mov_b64_dpp row_newbcast + v_fma_f64", out, cyc, 0);
+    run<CNDMASK2>("2 v_cndmask_b32 (select a double)", out, cyc, 0);
     return 0;
 }
