@@ -165,12 +165,16 @@ static const double CK_E[6] = {37.0 / 378 - 2825.0 / 27648, 0, 250.0 / 621 - 185
 /* An explicit embedded Runge-Kutta pair as data: what cashkarp_aug_day's driver (erk_aug_day) steps with.  Cash-Karp is the one
  * the device kernels implement; Tsitouras 5(4) exists here for the round-3 probe only (tools/probe_pair.py: would another pair
  * need fewer right-hand sides under the same knee-aware controller?  oracle-only integrator id ORACLE_INTEG_TSIT5_AUG). */
-#define ERK_MAX_STAGES 7
+#define ERK_MAX_STAGES 13
 typedef struct {
     int ns;                          /* stages */
     int fsal;                        /* 1: the last stage is the derivative at the new point (b == last row of A) */
     double A[ERK_MAX_STAGES][ERK_MAX_STAGES - 1];
     double B[ERK_MAX_STAGES], E[ERK_MAX_STAGES];      /* weights of the higher-order solution; b - bhat */
+    double E3[ERK_MAX_STAGES];       /* second estimator (Dormand-Prince 8(5,3) only; all zero otherwise): the error of a component is then
+                                        |e5|^2 / sqrt(e5^2 + 0.01 e3^2), Hairer's combination, applied per component under the max norm */
+    int two_est;
+    double err_exp;                  /* step-size factor = SAFETY * err^err_exp: -1/5 for the 5(4) pairs, -1/8 for the 8(5,3) pair */
 } erk_tableau;
 
 static const erk_tableau TAB_CASHKARP = {
@@ -178,7 +182,8 @@ static const erk_tableau TAB_CASHKARP = {
     {{0}, {1.0 / 5}, {3.0 / 40, 9.0 / 40}, {3.0 / 10, -9.0 / 10, 6.0 / 5}, {-11.0 / 54, 5.0 / 2, -70.0 / 27, 35.0 / 27},
      {1631.0 / 55296, 175.0 / 512, 575.0 / 13824, 44275.0 / 110592, 253.0 / 4096}},
     {37.0 / 378, 0, 250.0 / 621, 125.0 / 594, 0, 512.0 / 1771},
-    {37.0 / 378 - 2825.0 / 27648, 0, 250.0 / 621 - 18575.0 / 48384, 125.0 / 594 - 13525.0 / 55296, -277.0 / 14336, 512.0 / 1771 - 1.0 / 4}};
+    {37.0 / 378 - 2825.0 / 27648, 0, 250.0 / 621 - 18575.0 / 48384, 125.0 / 594 - 13525.0 / 55296, -277.0 / 14336, 512.0 / 1771 - 1.0 / 4},
+    {0}, 0, -0.2};
 
 /* Ch. Tsitouras, "Runge-Kutta pairs of order 5(4) satisfying only the first column simplifying assumption", Computers &
  * Mathematics with Applications 62 (2011) 770-775.  7 stages, FSAL: 6 new right-hand sides per step.  (The 17 order
@@ -192,8 +197,29 @@ static const erk_tableau TAB_TSIT5 = {
      {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}},
     {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774, 0.0},
     {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629, 0.5823571654525552,
-     -0.45808210592918697, 0.015151515151515152}};
+     -0.45808210592918697, 0.015151515151515152},
+    {0}, 0, -0.2};
 #define ORACLE_INTEG_TSIT5_AUG 12      /* not in include/simplyp.h: a probe of this file only */
+#define ORACLE_INTEG_DOP853_AUG 13     /* likewise: Dormand-Prince 8(5,3) under the same controller */
+#include "dop853_tableau.inc"
+static erk_tableau TAB_DOP853;
+static int tab_dop853_ready = 0;
+static const erk_tableau* tab_dop853(void)
+{
+    if (!tab_dop853_ready) {
+#pragma omp critical
+        {
+            memset(&TAB_DOP853, 0, sizeof(TAB_DOP853));
+            TAB_DOP853.ns = 13; TAB_DOP853.fsal = 1; TAB_DOP853.two_est = 1; TAB_DOP853.err_exp = -0.125;
+            for (int s = 0; s < 13; ++s) {
+                for (int j = 0; j < 12; ++j) TAB_DOP853.A[s][j] = DOP853_A[s][j];
+                TAB_DOP853.B[s] = DOP853_B[s]; TAB_DOP853.E[s] = DOP853_E5[s]; TAB_DOP853.E3[s] = DOP853_E3[s];
+            }
+            tab_dop853_ready = 1;
+        }
+    }
+    return &TAB_DOP853;
+}
 
 static int state_finite(const double* y)
 {   /* the 8 carried states (slots 0-4, 6, 8, 10) */
@@ -407,8 +433,8 @@ static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, 
         st->rhs += (uint64_t)(ns - 1);
         double err = 0.0; int bad = 0;
         for (int i = 0; i < NZ; ++i) {
-            double inc = 0.0, ee = 0.0;
-            for (int s = 0; s < ns; ++s) { inc += tab->B[s] * k[s][i]; ee += tab->E[s] * k[s][i]; }
+            double inc = 0.0, ee = 0.0, e3 = 0.0;
+            for (int s = 0; s < ns; ++s) { inc += tab->B[s] * k[s][i]; ee += tab->E[s] * k[s][i]; e3 += tab->E3[s] * k[s][i]; }
             zn[i] = z[i] + hh * inc;
             /* error norm: the 7 physical states (see below), and Qr**k_M (z[10]) at AUG_AUX_WEIGHT x the tolerance: on a day
              * when a nearly dry reach is wetted it grows 200-fold, and its own truncation error then showed in the sediment
@@ -426,6 +452,10 @@ static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, 
             double sc = atol + rtol * w;
             if (i == 10) sc = AUG_AUX_WEIGHT * atol + (AUG_AUX_WEIGHT * rtol) * w;
             double r = fabs(hh * ee) / sc;
+            if (tab->two_est) {
+                const double r3 = fabs(hh * e3) / sc, den = sqrt(r * r + 0.01 * r3 * r3);
+                r = den > 0.0 ? r * r / den : 0.0;
+            }
             if (r > err) err = r;
         }
         if (kink_gw) err *= targeted ? AUG_KNEE_GW : AUG_KINK_GW;     /* a crossing the first slope did not announce: accepted only if short */
@@ -457,7 +487,7 @@ static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, 
         double fac;
         if (bad) fac = SIMPLYP_CTRL_FAC_MIN;
         else if (err == 0.0) fac = SIMPLYP_CTRL_FAC_MAX;
-        else { fac = SIMPLYP_CTRL_SAFETY * pow(err, -0.2); if (fac < SIMPLYP_CTRL_FAC_MIN) fac = SIMPLYP_CTRL_FAC_MIN; if (fac > SIMPLYP_CTRL_FAC_MAX) fac = SIMPLYP_CTRL_FAC_MAX; }
+        else { fac = SIMPLYP_CTRL_SAFETY * pow(err, tab->err_exp); if (fac < SIMPLYP_CTRL_FAC_MIN) fac = SIMPLYP_CTRL_FAC_MIN; if (fac > SIMPLYP_CTRL_FAC_MAX) fac = SIMPLYP_CTRL_FAC_MAX; }
         /* (a step that was cut to end at a knee and accepted does not shorten the step size carried on) */
         if (!(targeted && !bad && err <= 1.0 && hh * fac < h)) h = hh * fac;
     }
@@ -825,8 +855,10 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
                 cashkarp_aug_f32_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else if (n_integ == ORACLE_INTEG_TSIT5_AUG)
                 erk_aug_day(&TAB_TSIT5, y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
+            else if (n_integ == ORACLE_INTEG_DOP853_AUG)
+                erk_aug_day(tab_dop853(), y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else cashkarp_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
-            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG && n_integ != SIMPLYP_INTEG_CASHKARP_AUG_F32 && n_integ != ORACLE_INTEG_TSIT5_AUG) {
+            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG && n_integ != SIMPLYP_INTEG_CASHKARP_AUG_F32 && n_integ != ORACLE_INTEG_TSIT5_AUG && n_integ != ORACLE_INTEG_DOP853_AUG) {
                 /* Drift control (not in the reference).  The reference's own equations (:127-131) imply
                  * dVr = dQr * (1-b_Q) L / (a_Q 86400 Qr^b_Q), and Vr0 (:457-459) starts on that curve, so
                  * Vr == L Qr^(1-b_Q) / (a_Q 86400) for all t; Vr has no restoring term and a one-step

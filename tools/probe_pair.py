@@ -1,7 +1,9 @@
 """CPU: would another embedded 5(4) pair need fewer right-hand sides than Cash-Karp under the same knee-aware controller?
 Tsitouras 5(4) (7 stages, first-same-as-last: 6 new right-hand sides per attempt, like Cash-Karp) against Cash-Karp on members of
 the C3 bench ensemble, 30 years, REACH-5: right-hand sides per catchment-day against the WORST member's error (truth: Cash-Karp
-at rtol 1e-11).  The oracle carries the Tsit5 tableau for this probe only (ORACLE_INTEG_TSIT5_AUG = 12).
+at rtol 1e-11).  Also Dormand-Prince 8(5,3) (12 new right-hand sides per attempt; would suit the four-lane kernel, whose lanes hold
+three components each).  The oracle carries both tableaux for this probe only (ORACLE_INTEG_TSIT5_AUG = 12, _DOP853_AUG = 13);
+SIMPLYP_PROBE_PAIRS=dop853,cash-karp selects.
 Usage: python tools/probe_pair.py [members [threads]]"""
 import os, sys, time
 import numpy as np
@@ -27,7 +29,9 @@ def run(integ, rtol, atol):
 
 truth, st, dt = run(2, 1e-11, 1e-13)
 print('truth: Cash-Karp rtol 1e-11: %.1f rhs/cd, %.0f s' % (st['rhs_evals'] / (E * D), dt), flush=True)
-for name, integ, rtols in (('cash-karp', 2, (1e-7, 2e-7, 5e-8)), ('tsit5', 12, (1e-7, 2e-7, 4e-7, 5e-8))):
+PAIRS = (('cash-karp', 2, (1e-7, 2e-7, 5e-8)), ('tsit5', 12, (1e-7, 2e-7, 4e-7, 5e-8)), ('dop853', 13, (1e-6, 3e-7, 1e-7, 3e-8, 1e-8, 1e-9)))
+only = os.environ.get('SIMPLYP_PROBE_PAIRS')
+for name, integ, rtols in [p for p in PAIRS if not only or p[0] in only.split(',')]:
     for rtol in rtols:
         out, st, dt = run(integ, rtol, 1e-12)
         rel = np.abs(out - truth) / np.maximum(np.abs(truth), 1e-300)
