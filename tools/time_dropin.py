@@ -1,5 +1,7 @@
 import sys, time, io, contextlib
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import helpers
 import simplyp_amd as sp
 for name in ('tarland_1981_2010_dynamic', 'tarland_2004_dynamic', 'confluence3_nc_2004'):
