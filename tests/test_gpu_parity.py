@@ -548,7 +548,7 @@ def test_c4_chain_pipelined_matches_chain_kernel_and_oracle(engine0, oracle_lib)
     """BASELINE config C4's shape through the pipelined queue (auto: a 256-reach chain with few members cannot fill
     the chip from one thread per member): 256-deep pipeline, 2-chunk routing rings; equals the in-kernel chain walk
     bit for bit and the oracle to 10 x rtol."""
-    pr = synthetic.c4_problem(70, n_reaches=256, n_days=1100)
+    pr = synthetic.c4_problem(70, n_reaches=256, n_days=700)
     out, status, st = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'],
                                   pr['up_ptr'], pr['up_idx'], pr['opts'], out_reaches=pr['out_reaches'])
     assert st['queued'] == 1 and int(status.max()) == 0
@@ -753,9 +753,9 @@ def test_config_c4_full_shape(engine0, oracle_lib):
     """BASELINE config C4's FULL shape except for the ensemble size -- 256-reach chain x 4 land-use classes x 18 262 days (50
     years), 1 000 members (the bench runs 10 000) -- through the path the bench takes: pipelined task queue (256-deep), cost-
     ordered member groups, slot-order table of the outlet reach.  Size-independent properties: no member flagged; every value
-    finite and the outlet carries the chain's accumulated flow; the first 512 days equal, bit for bit, what the in-kernel chain
+    finite and the outlet carries the chain's accumulated flow; the first 384 days equal, bit for bit, what the in-kernel chain
     walk (one thread per member, no queue) computes for the same members; two members against the CPU oracle over the first
-    12 years (10 x rtol)."""
+    8 years (10 x rtol)."""
     import torch
     E, S, D = 1000, 256, 18262
     pr = synthetic.c4_problem(E, n_reaches=S, n_days=D, solver=dict(out_slot_order=1))
@@ -769,18 +769,18 @@ def test_config_c4_full_shape(engine0, oracle_lib):
     slot_of = torch.empty(E, dtype=torch.long, device=out.device)
     slot_of[mos] = torch.arange(E, device=out.device)
     assert float(out[1].mean()) > 5.0              # mm/d over the outlet's own area: the flow of 256 sub-catchments
-    # the chain kernel on a slice: 64 members, the first 512 days (results of a day do not depend on later days)
+    # the chain kernel on a slice: 64 members, the first 384 days (results of a day do not depend on later days)
     sl = np.arange(64) * 15
-    short = dict(pr, forcing=np.ascontiguousarray(pr['forcing'][:, :, :512]), doy=np.ascontiguousarray(pr['doy'][:512]),
+    short = dict(pr, forcing=np.ascontiguousarray(pr['forcing'][:, :, :384]), doy=np.ascontiguousarray(pr['doy'][:384]),
                  member_params=np.ascontiguousarray(pr['member_params'][:, sl]), reach_params=np.ascontiguousarray(pr['reach_params'][:, :, sl]))
     short['opts'] = abi.make_opts(dict(time_chunk_days=-1, balance=0), dynamic_epc0=True, dynamic_erod=True, run_mode_cal=True,
                                   sc_qr0=pr['opts'].sc_qr0, out_mask=pr['opts'].out_mask)
     ref, rs, rst = engine0.run(short['forcing'], short['doy'], short['member_params'], short['reach_params'],
                                short['up_ptr'], short['up_idx'], short['opts'], out_reaches=pr['out_reaches'])
     assert rst['queued'] == 0 and int(rs.max()) == 0
-    assert bool(torch.equal(ref, out[:, :512][..., slot_of[torch.as_tensor(sl, device=out.device)]]))
-    # two members against the CPU oracle over the first 12 years (the oracle takes ~5 s per member and decade of this network)
-    pick, Dc = [7, 512], 4383
+    assert bool(torch.equal(ref, out[:, :384][..., slot_of[torch.as_tensor(sl, device=out.device)]]))
+    # two members against the CPU oracle over the first 8 years (the oracle takes ~5 s per member and decade of this network)
+    pick, Dc = [7, 512], 2922
     sub = dict(pr, forcing=np.ascontiguousarray(pr['forcing'][:, :, :Dc]), doy=np.ascontiguousarray(pr['doy'][:Dc]),
                member_params=pr['member_params'][:, pick], reach_params=pr['reach_params'][:, :, pick])
     cref, cstatus, _ = cpu_run(oracle_lib, sub, out_reaches=pr['out_reaches'], n_threads=2)
