@@ -370,3 +370,26 @@ def test_deferred_sync_lets_the_callers_work_run_beside_the_copy_tail(engine0):
     assert np.array_equal(host, ref.cpu().numpy(), equal_nan=True)
     with pytest.raises(engine.EngineError, match='non-default torch stream'):
         run(engine0, m, defer_sync=True)
+
+
+def test_ensemble_entry_falls_back_to_a_pageable_host_table(engine0, monkeypatch):
+    """run_simply_p_ensemble(to_host=True) page-locks the whole output table; on a host that cannot lock that much
+    (hipHostMalloc fails, or the table exceeds 60 % of the available memory) it must fall back to an ordinary array -- which
+    simplyp_stream_out accepts -- and return the same table."""
+    import simplyp_amd as sp
+    args = lambda: tuple(x.copy() for x in helpers.scenario_inputs('tarland_2004_dynamic'))
+    fc = np.array([280.0, 290.0, 300.0, 310.0])
+    want = sp.run_simply_p_ensemble(*args(), overrides={'fc': fc})
+    calls = {'n': 0}
+    real = engine.pinned_empty
+
+    def refuse_big(shape, dtype=np.float64):
+        n = int(np.prod(shape))
+        if n > 1000:                      # the output table; the small parameter tables still get pinned memory
+            calls['n'] += 1
+            raise engine.EngineError("simplyp_host_alloc(%d bytes) failed (pinned host memory)" % (n * 8))
+        return real(shape, dtype)
+    monkeypatch.setattr(engine, 'pinned_empty', refuse_big)
+    got = sp.run_simply_p_ensemble(*args(), overrides={'fc': fc})
+    assert calls['n'] >= 1
+    assert isinstance(got['data'], np.ndarray) and np.array_equal(got['data'], want['data']) and np.array_equal(got['status'], want['status'])
