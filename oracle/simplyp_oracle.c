@@ -458,6 +458,10 @@ static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, 
             }
             if (r > err) err = r;
         }
+        {   /* expansive reach (SIMPLYP_CTRL_EXPAND, SysAug::EXPAND): d(dQr/dt)/dQr > 0  <=>  b_Q x (net inflow) > Qr; k[0][3] = inflow cQ pb */
+            const double cQ = p->a_Q * (8.64 * 10000) / ((1 - p->b_Q) * (p->L_reach));
+            if (p->b_Q * k[0][3] > z[3] * (cQ * z[9])) err *= SIMPLYP_CTRL_EXPAND;
+        }
         if (kink_gw) err *= targeted ? AUG_KNEE_GW : AUG_KINK_GW;     /* a crossing the first slope did not announce: accepted only if short */
         else if (kink && !targeted) err *= AUG_KINK_SOIL;            /* (a step that ends at a soil knee: no inflation) */
         if (!(err < 1.0e300)) bad = 1;

@@ -381,6 +381,10 @@ struct SysAug {
                             KNEE_GW = SIMPLYP_CTRL_KNEE_GW;
     static constexpr double DAY_START = SIMPLYP_CTRL_DAY_START;
     static constexpr double AUX_WEIGHT = SIMPLYP_CTRL_AUX_WEIGHT;
+    // Expansive reach (include/simplyp_controller.h): where the flow equation amplifies errors instead of damping them -- a nearly dry
+    // reach being wetted, b_Q x (net inflow) > Qr -- a step's estimate is multiplied by EXPAND.  With z[9] = cQ Qr**b_Q the first
+    // slope of Qr is k1[3] = (net inflow) z[9], so the test is b_Q k1[3] > Qr z[9]: two multiplications and a compare.
+    static constexpr double EXPAND = SIMPLYP_CTRL_EXPAND;
     // z[9] carries cQ * Qr**b_Q (the factor the flow equation multiplies it with, folded into the state: one multiplication
     // less per right-hand side; its ODE is linear in it, so the scaling changes nothing else)
     static __device__ __forceinline__ void resync(double (&z)[11], const DayConst& c)
@@ -611,6 +615,8 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
             const bool cs = hs < look, cg = hg < look;
             const bool gw = cg || (cs && ugd > (R)0);
             kfac = gw ? (targeted ? (R)SYS::KNEE_GW : (R)SYS::KINK_GW) : ((cs && !targeted) ? (R)SYS::KINK_SOIL : (R)1);
+            // expansive reach: the estimate of a step that starts there is multiplied by EXPAND
+            kfac = kfac * ((c.bQ * k1[3] > y[3] * y[9]) ? (R)SYS::EXPAND : (R)1);
         }
         {
             const R h21 = hh * a21;
@@ -1007,6 +1013,11 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
             kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(2, 3, 0, 1), 0xf, 0xf, true);
             const bool gw = (kink & 2) != 0 || (kink & 5) == 5;
             kfac = gw ? (targeted ? SysAug::KNEE_GW : SysAug::KINK_GW) : (((kink & 1) && !targeted) ? SysAug::KINK_SOIL : 1.0);
+        }
+        {
+            // expansive reach (SysAug::EXPAND): the reach lane holds Qr, cQ Qr**b_Q and the first slope of Qr; its verdict goes to the quad
+            const int expanding = __builtin_amdgcn_update_dpp(0, (k.c1 * k1[0] > y[0] * y[1]) ? 1 : 0, SP_QP(3, 3, 3, 3), 0xf, 0xf, true);
+            kfac = kfac * (expanding ? SysAug::EXPAND : 1.0);
         }
         {
             const R h21 = hh * a21;

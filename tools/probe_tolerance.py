@@ -1,7 +1,8 @@
 """Error of the working tolerances across the bench's Monte-Carlo ensemble: each member's max relative error over the
 REACH-5 daily columns (30 years) against the same kernel at rtol 1e-11 / atol 1e-13 (which the goldens pin to the
 reference's tight solution to 1e-9).  SIMPLYP_PROBE_SEED=<int> draws the ensemble with another seed (held-out draws: the bench's
-ranks > 0 run C3_SEED + rank); SIMPLYP_PROBE_SNOW=1 perturbs f_DDSM / D_snow_0 too and runs the in-kernel snow module.
+ranks > 0 run C3_SEED + rank); SIMPLYP_PROBE_SNOW=1 perturbs f_DDSM / D_snow_0 too and runs the in-kernel snow module; SIMPLYP_PROBE_PSCALE=s multiplies the
+precipitation by s and divides PET by s (a wetter / drier climate than Tarland's).
 Usage: python tools/probe_tolerance.py [members [rtol ...]]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,12 +13,17 @@ from simplyp_amd import engine, synthetic
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 SEED = int(os.environ.get('SIMPLYP_PROBE_SEED', synthetic.C3_SEED))
 SNOW = os.environ.get('SIMPLYP_PROBE_SNOW') == '1'
+PSCALE = float(os.environ.get('SIMPLYP_PROBE_PSCALE', '1'))          # precipitation x this, PET / this: another climate
 eng = engine.get_engine(0)
-print('seed', SEED, 'snow' if SNOW else '', flush=True)
+print('seed', SEED, 'snow' if SNOW else '', 'P x %g, PET / %g' % (PSCALE, PSCALE) if PSCALE != 1 else '', flush=True)
 
 
 def run(solver):
     pr = synthetic.c3_problem(E, seed=SEED, solver=dict(solver, balance=0, time_chunk_days=-1))
+    if PSCALE != 1:
+        pr['forcing'] = pr['forcing'].copy()
+        pr['forcing'][:, 0] *= PSCALE
+        pr['forcing'][:, 1] /= PSCALE
     if SNOW:      # the snow module per member inside the kernel, snow parameters drawn per member
         from simplyp_amd import marshal
         met = pr['met']
