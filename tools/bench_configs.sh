@@ -8,7 +8,7 @@ mkdir -p $O
 timeout -k 10 300 python bench.py --config c5 --steps 3 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err
 for n in 12500 25000 50000; do timeout -k 10 300 python bench.py --members $n --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c3_shard_$n.json 2> $O/shard_$n.err; done
 timeout -k 10 200 python tools/time_dropin.py > $O/dropin.log 2>&1; cat $O/dropin.log
-timeout -k 10 900 python bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+[ -n "$SKIP_C4" ] || timeout -k 10 900 python bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
 python - "$O" <<'PY'
 import json, glob, sys
 for f in sorted(glob.glob(sys.argv[1] + '/bench_*.json')):
