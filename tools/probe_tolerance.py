@@ -2,7 +2,8 @@
 REACH-5 daily columns (30 years) against the same kernel at rtol 1e-11 / atol 1e-13 (which the goldens pin to the
 reference's tight solution to 1e-9).  SIMPLYP_PROBE_SEED=<int> draws the ensemble with another seed (held-out draws: the bench's
 ranks > 0 run C3_SEED + rank); SIMPLYP_PROBE_SNOW=1 perturbs f_DDSM / D_snow_0 too and runs the in-kernel snow module; SIMPLYP_PROBE_PSCALE=s multiplies the
-precipitation by s and divides PET by s (a wetter / drier climate than Tarland's).
+precipitation by s and divides PET by s (a wetter / drier climate than Tarland's); SIMPLYP_PROBE_WIDE=w widens the draws of the time
+constants and rates (T_s, T_g, a_Q, E_M, f_quick) by a further log-uniform factor in [1/w, w].
 Usage: python tools/probe_tolerance.py [members [rtol ...]]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,12 +15,18 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 SEED = int(os.environ.get('SIMPLYP_PROBE_SEED', synthetic.C3_SEED))
 SNOW = os.environ.get('SIMPLYP_PROBE_SNOW') == '1'
 PSCALE = float(os.environ.get('SIMPLYP_PROBE_PSCALE', '1'))          # precipitation x this, PET / this: another climate
+WIDE = float(os.environ.get('SIMPLYP_PROBE_WIDE', '1'))              # every drawn time constant / rate x a further log-uniform factor in [1/WIDE, WIDE]
 eng = engine.get_engine(0)
-print('seed', SEED, 'snow' if SNOW else '', 'P x %g, PET / %g' % (PSCALE, PSCALE) if PSCALE != 1 else '', flush=True)
+print('seed', SEED, 'snow' if SNOW else '', 'wide x/%g' % WIDE if WIDE != 1 else '', 'P x %g, PET / %g' % (PSCALE, PSCALE) if PSCALE != 1 else '', flush=True)
 
 
 def run(solver):
     pr = synthetic.c3_problem(E, seed=SEED, solver=dict(solver, balance=0, time_chunk_days=-1))
+    if WIDE != 1:      # a wider parameter distribution than BASELINE C3's: soil, groundwater and reach time scales
+        from simplyp_amd import marshal
+        rng = np.random.default_rng(SEED + 2000)
+        for name in ('T_s_A', 'T_s_S', 'T_g', 'a_Q', 'E_M', 'f_quick'):
+            pr['member_params'][marshal.PM_NAMES.index(name)] *= np.exp(rng.uniform(-np.log(WIDE), np.log(WIDE), E))
     if PSCALE != 1:
         pr['forcing'] = pr['forcing'].copy()
         pr['forcing'][:, 0] *= PSCALE
