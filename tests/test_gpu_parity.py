@@ -787,3 +787,35 @@ def test_config_c4_full_shape(engine0, oracle_lib):
     assert cstatus.max() == 0
     got = out[:, :Dc][..., slot_of[torch.as_tensor(pick, device=out.device)]].cpu().numpy()
     assert helpers.max_rel_err(got, cref, floor=FLOOR) < helpers.TOL_WORKING
+
+
+def dry_climate_members(n=256, seed=synthetic.C3_SEED + 12, pscale=0.6):
+    """The n members of a 100 000-member C3 draw with the smallest Qg_min, on a climate with `pscale` x the precipitation and
+    1 / pscale x the PET of Tarland's: reaches that nearly dry up and are wetted again -- where the flow equation amplifies errors
+    (include/simplyp_controller.h: SIMPLYP_CTRL_EXPAND)."""
+    pr = synthetic.c3_problem(100000, seed=seed)
+    pr['forcing'] = pr['forcing'].copy()
+    pr['forcing'][:, 0] *= pscale
+    pr['forcing'][:, 1] /= pscale
+    sel = np.argsort(pr['member_params'][marshal.PM_NAMES.index('Qg_min')])[:n]
+    return dict(pr, member_params=np.ascontiguousarray(pr['member_params'][:, sel]),
+                reach_params=np.ascontiguousarray(pr['reach_params'][:, :, sel])), sel
+
+
+@pytest.mark.parametrize('lanes', [1, 4])
+def test_expansive_reach_on_a_drier_climate(engine0, lanes):
+    """Round 3: on a climate with 0.6 x Tarland's precipitation 31 of 100 000 members were above 1e-6 (worst 8.6e-6), all among those
+    with Qg_min ~ 0 on days when a nearly dry reach is wetted.  With the controller's expansive-reach rule the 256 driest members stay
+    below 1e-6 against the same kernel at rtol 1e-11 (measured 4.2e-7), one lane and four lanes per member."""
+    m, sel = dry_climate_members()
+    m['opts'].lanes_per_member = lanes
+    rtol, atol = m['opts'].rtol, m['opts'].atol
+    m['opts'].rtol, m['opts'].atol = 1e-11, 1e-13
+    truth, st, _ = gpu_run(engine0, m)
+    assert st.max() == 0
+    m['opts'].rtol, m['opts'].atol = rtol, atol
+    got, st, stats = gpu_run(engine0, m)
+    assert st.max() == 0 and stats['lanes_per_member'] == lanes
+    worst = (np.abs(got - truth) / np.maximum(np.abs(truth), 1e-300)).max(axis=(0, 1, 2))
+    assert worst.max() < 1e-6, (float(worst.max()), int(sel[worst.argmax()]))
+    assert float(truth[1].min()) < 1e-3          # the reach does nearly dry up (Qr in mm/d)

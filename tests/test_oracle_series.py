@@ -244,3 +244,28 @@ def test_oracle_default_solver_against_reference_tables_of_single_members(oracle
     worst = [max(helpers.max_rel_err(out[marshal.OUT_COLUMNS.index(c), :, 0, k], tables[k][:, j], floor=1e-300)
                  for j, c in enumerate(REACH_COLS)) for k in range(len(tables))]
     assert max(worst) < bar, dict(zip(m['members'], worst))
+
+
+def test_oracle_expansive_reach_on_a_drier_climate(oracle_lib):
+    """The CPU mirror of the controller's expansive-reach rule (include/simplyp_controller.h: SIMPLYP_CTRL_EXPAND): the 24 members
+    of a 100 000-member draw with the smallest Qg_min on a climate with 0.6 x Tarland's precipitation -- reaches that nearly dry up
+    and are wetted again -- stay below 1e-6 against the converged solution (before the rule: up to 8.6e-6)."""
+    from simplyp_amd import synthetic
+    pr = synthetic.c3_problem(100000, seed=synthetic.C3_SEED + 12)
+    pr['forcing'] = pr['forcing'].copy()
+    pr['forcing'][:, 0] *= 0.6
+    pr['forcing'][:, 1] /= 0.6
+    sel = np.argsort(pr['member_params'][marshal.PM_NAMES.index('Qg_min')])[:24]
+    mp = np.ascontiguousarray(pr['member_params'][:, sel]); rp = np.ascontiguousarray(pr['reach_params'][:, :, sel])
+
+    def run(rtol, atol):
+        pr['opts'].rtol, pr['opts'].atol = rtol, atol
+        out, status, _ = oracle_lib.run(pr['forcing'], pr['doy'], mp, rp, pr['up_ptr'], pr['up_idx'], pr['opts'], n_threads=8)
+        assert status.max() == 0
+        return out
+    rtol, atol = pr['opts'].rtol, pr['opts'].atol
+    truth = run(1e-11, 1e-13)
+    out = run(rtol, atol)
+    worst = (np.abs(out - truth) / np.maximum(np.abs(truth), 1e-300)).max(axis=(0, 1, 2))
+    assert worst.max() < 1e-6, dict(zip(sel.tolist(), worst))
+    assert truth[1].min() < 1e-3
