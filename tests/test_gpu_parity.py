@@ -687,14 +687,14 @@ def test_knee_aware_controller_on_the_members_that_needed_it(engine0, oracle_lib
 # time): the six bench members the knee-aware controller's constants were tuned on, over all 30 years (knee_members.npz); 16
 # members of a draw nothing was tuned on, seed C3_SEED + 7 = what rank 7 of a weak-scaling bench runs (heldout_members.npz); 8
 # members of the bench's own draw (monte_carlo_members.npz).  The kernel -- one lane and four lanes per member -- must meet
-# north_star's bar, <= 1e-6 relative on all 9 reach outputs, on every one of them.
+# north_star's bar, <= 1e-6 relative on all 9 reach outputs, on every one of them (asserted at 5e-7; measured 2.3e-7 / 1.6e-7 / < 5e-7).
 
 def _worst_per_member(got, tables, cols=REACH_COLS):
     return [max(helpers.max_rel_err(got[marshal.OUT_COLUMNS.index(c), :, 0, k], tables[k][:, j], floor=1e-300)
                 for j, c in enumerate(cols)) for k in range(len(tables))]
 
 
-@pytest.mark.parametrize('fname,bar', [('knee_members.npz', 1e-6), ('heldout_members.npz', 5e-7)])
+@pytest.mark.parametrize('fname,bar', [('knee_members.npz', 5e-7), ('heldout_members.npz', 5e-7)])
 @pytest.mark.parametrize('lanes', [1, 4])
 def test_default_solver_against_reference_tables_of_single_members(engine0, fname, bar, lanes):
     m, tables = helpers.member_fixture_problem(fname, solver=dict(lanes_per_member=lanes))
