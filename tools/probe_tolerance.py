@@ -15,9 +15,10 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 SEED = int(os.environ.get('SIMPLYP_PROBE_SEED', synthetic.C3_SEED))
 SNOW = os.environ.get('SIMPLYP_PROBE_SNOW') == '1'
 PSCALE = float(os.environ.get('SIMPLYP_PROBE_PSCALE', '1'))          # precipitation x this, PET / this: another climate
+TSHIFT = float(os.environ.get('SIMPLYP_PROBE_TSHIFT', '0'))         # with SIMPLYP_PROBE_SNOW: air temperature + this many degrees (a colder / warmer winter)
 WIDE = float(os.environ.get('SIMPLYP_PROBE_WIDE', '1'))              # every drawn time constant / rate x a further log-uniform factor in [1/WIDE, WIDE]
 eng = engine.get_engine(0)
-print('seed', SEED, 'snow' if SNOW else '', 'wide x/%g' % WIDE if WIDE != 1 else '', 'P x %g, PET / %g' % (PSCALE, PSCALE) if PSCALE != 1 else '', flush=True)
+print('seed', SEED, ('snow, T_air %+g' % TSHIFT) if SNOW else '', 'wide x/%g' % WIDE if WIDE != 1 else '', 'P x %g, PET / %g' % (PSCALE, PSCALE) if PSCALE != 1 else '', flush=True)
 
 
 def run(solver):
@@ -27,7 +28,7 @@ def run(solver):
         rng = np.random.default_rng(SEED + 2000)
         for name in ('T_s_A', 'T_s_S', 'T_g', 'a_Q', 'E_M', 'f_quick'):
             pr['member_params'][marshal.PM_NAMES.index(name)] *= np.exp(rng.uniform(-np.log(WIDE), np.log(WIDE), E))
-    if PSCALE != 1:
+    if PSCALE != 1 and not SNOW:
         pr['forcing'] = pr['forcing'].copy()
         pr['forcing'][:, 0] *= PSCALE
         pr['forcing'][:, 1] /= PSCALE
@@ -35,6 +36,11 @@ def run(solver):
         from simplyp_amd import marshal
         met = pr['met']
         pr['forcing'], pr['doy'] = marshal.forcing_arrays(met, snow=True)
+        pr['forcing'] = pr['forcing'].copy()
+        pr['forcing'][:, 2] += TSHIFT
+        if PSCALE != 1:
+            pr['forcing'][:, 0] *= PSCALE
+            pr['forcing'][:, 1] /= PSCALE
         pr['opts'].snow = 1
         rng = np.random.default_rng(SEED + 1000)
         pr['member_params'][marshal.PM_NAMES.index('f_DDSM')] = rng.uniform(1.0, 5.0, E)
