@@ -25,8 +25,11 @@ c3: BASELINE C3 is "a 100k-member ensemble sharded across 1 -> 8 GPUs"); weak = 
 (default for the other configs).  With the default strong C3 line at N > 1 the weak figure (100 000 members per GPU) is
 measured after the timed region and carried in the same line as `value_weak`.
 
-After the timed region of the default run the line also gets `secondary`: BASELINE configs C2 and C5 and a C3 pass that
-leaves only the members' goodness-of-fit table (simplyp_gof), a few passes each, so that the driver's run sees them.
+After the timed region of the default run the line also gets `secondary`: BASELINE configs C2, C5 (a few passes each) and C4
+at its stated size (ONE pass of 10 000 members x 256 reaches x 18 262 days), a C3 pass that leaves only the members'
+goodness-of-fit table (simplyp_gof), and `strong_1m`: ONE 1 000 000-member fp64 ensemble split over the ranks (annual sums) --
+the leg that can show strong scaling.  C4, C5 and strong_1m carry a sample of their benchmarked table checked against the CPU
+oracle.  The whole default run takes about three minutes.
 
 With --gpus N > 1 from a plain shell the script starts its own N ranks (torch.distributed.run) before anything touches
 the GPU and relays rank 0's line.  Prints ONE JSON line on rank 0.
@@ -72,6 +75,13 @@ CONFIGS = {
                parity_grade=False, scaling='weak',
                what="one GPU's share of the 1M-member Tarland ensemble (BASELINE config C5): fp32 Runge-Kutta stages + fp64 "
                     "daily integrals / soil P / carried state, rtol=%(rtol)g, output = 30 annual sums of Qr and the 3 fluxes"),
+    # the one leg of the N > 1 line that CAN scale strongly: an ensemble large enough that an eighth of it still fills a chip
+    # (125 000 members = two rounds of 64-member waves on 1024 SIMDs); fp64, default solver, C3's distribution
+    'strong_1m': dict(members=1000000, bytes_per_cd=16.0 + 4 * 8 * 30 / 10957.0, dtype='f64', out='annual sums of the 4 fluxes',
+                      parity_grade=True, scaling='strong',
+                      what="ONE 1 000 000-member Tarland Monte-Carlo ensemble (C3's distribution and solver: fp64 Cash-Karp 5(4) on "
+                           "the augmented system, rtol=%(rtol)g), 30-yr daily 1981-2010, split contiguously over the GPUs, output = "
+                           "30 annual sums of Qr and the 3 fluxes per member"),
 }
 
 
@@ -93,7 +103,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-stream', action='store_true', help='leave the output table in HBM (value = device-resident rate)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the accuracy checks (keeps a profile to one kernel shape)')
-    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary legs (c2, c5, c3 -> goodness of fit only, value_weak)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary legs (c2, c5, c4, strong_1m, c3 -> goodness of fit only, value_weak)')
+    ap.add_argument('--secondary-scale', type=float, default=None,
+                    help='rehearsals: run the secondary legs (also beside a non-default --members) with their member counts times this factor')
     return ap.parse_args(argv)
 
 
@@ -149,8 +161,12 @@ def build_problem(cfg, n_members, seed_offset, args):
                                   seed=synthetic.C4_SEED + seed_offset, solver=dict(out_slot_order=1))
     else:
         fluxes = ['Qr', 'Msus_kg/day', 'TDP_kg/day', 'PP_kg/day']
-        pr = synthetic.c3_problem(n_members, seed=20240603 + seed_offset, out_mask=marshal.mask_of_columns(fluxes),
-                                  solver=dict(integrator='cashkarp_aug_f32', rtol=1e-5, atol=1e-7, out_slot_order=1))
+        if cfg == 'strong_1m':
+            pr = synthetic.c3_problem(n_members, seed=synthetic.C3_SEED + 100 + seed_offset, out_mask=marshal.mask_of_columns(fluxes),
+                                      solver=dict(out_slot_order=1))
+        else:
+            pr = synthetic.c3_problem(n_members, seed=20240603 + seed_offset, out_mask=marshal.mask_of_columns(fluxes),
+                                      solver=dict(integrator='cashkarp_aug_f32', rtol=1e-5, atol=1e-7, out_slot_order=1))
         years = pr['met'].index.year.values
         periods, pod = np.unique(years, return_inverse=True)
         pr['opts'].n_periods = len(periods)
@@ -495,8 +511,8 @@ def main():
 
     # ---- secondary legs: only beside the default workload (the driver's run); every rank takes part ----
     secondary = {}
-    default_run = (args.config == 'c3' and args.members is None and args.rtol is None and args.chunk_days is None
-                   and args.lanes_per_member is None and not args.no_stream and not args.no_secondary)
+    default_run = (args.config == 'c3' and args.rtol is None and args.chunk_days is None and args.lanes_per_member is None
+                   and not args.no_stream and not args.no_secondary and (args.members is None or args.secondary_scale is not None))
     if default_run:
         secondary['c3_gof_only'] = leg_gof_only(b, leg)
     prob_main = leg.prob
@@ -505,6 +521,11 @@ def main():
     if default_run:
         secondary['c2'] = leg_secondary(b, 'c2')
         secondary['c5'] = leg_secondary(b, 'c5')
+        # C4 at its stated size: ONE pass, no warm-up (it takes over a minute; the one-time allocation of the routing ring
+        # buffers, ~0.1 s, is inside it)
+        secondary['c4'] = leg_secondary(b, 'c4', steps=1, warmup=0)
+        # ... and the one leg that can scale strongly: ONE 1M-member ensemble split over the ranks, one pass
+        secondary['strong_1m'] = leg_secondary(b, 'strong_1m', steps=1, warmup=0)
         vw = leg_value_weak(b, line, scaling)
         if rank == 0:
             line['value_weak'] = vw
@@ -522,25 +543,36 @@ def main():
         dist.destroy_process_group()
 
 
-def leg_secondary(b, config, steps=3):
-    """A BASELINE configuration beside the headline: every rank runs the config's single-GPU size (weak), `steps` timed passes
-    after one warm-up, table delivered to pinned host memory."""
+def leg_secondary(b, config, steps=3, warmup=1):
+    """A BASELINE configuration beside the headline, table delivered to pinned host memory, `steps` timed passes after `warmup`
+    untimed ones: every rank runs the config's single-GPU size (weak) -- or, for a config whose scaling is 'strong', ONE ensemble
+    of the config's size split contiguously over the ranks.  A sample of the benchmarked table goes through the CPU oracle."""
     import numpy as np
     cfg = CONFIGS[config]
-    leg = Leg(b, config, 'weak', cfg['members'], stream=True, seed_base=0)
-    leg.one_step(leg.host_out)
+    n_members = cfg['members'] if b.args.secondary_scale is None else max(b.world, int(round(cfg['members'] * b.args.secondary_scale)))
+    leg = Leg(b, config, cfg['scaling'] if config == 'strong_1m' else 'weak', n_members, stream=True, seed_base=0)
+    for _ in range(warmup):
+        leg.one_step(leg.host_out)
     elapsed, res, st = leg.timed(steps, leg.host_out, "secondary %s" % config)
+    k_ranks = b.per_rank(float(np.mean([s_['kernel_ms'] for s_ in st])))
     k_ms = float(np.mean([s['kernel_ms'] for s in st]))
     stats = res['stats']
     d = None
     if b.rank == 0:
         d = {"workload": cfg['what'] % dict(rtol=leg.opts.rtol) + "; %d members per GPU; output: %s" % (leg.e_local, cfg['out']),
              "value": leg.cd_per_step / (elapsed / steps), "unit": "catchment-days/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+             "warmup": warmup, "scaling": leg.scaling, "members_total": leg.e_total, "members_per_gpu": leg.e_local,
+             "reaches": leg.S, "days": leg.D, "per_rank": {"kernel_ms": [round(x, 3) for x in k_ranks]},
              "table": "pinned host memory" if leg.host_out is not None else "left in HBM (%s)" % leg.stream_note,
              "kernel": leg.kernel_name(stats), "kernel_ms": k_ms, "dtype": cfg['dtype'], "parity_grade": cfg['parity_grade'],
              "roofline": {"bound": "hbm", "frac": leg.roofline_frac(k_ms), "bytes_per_catchment_day": cfg['bytes_per_cd']},
              "rhs_evals_per_catchment_day": st[-1]['rhs_evals'] / leg.cd_rank, "simt_efficiency": stats.get('simt_efficiency'),
+             "rejected_per_step": (st[-1]['rejected'] / float(st[-1]['steps'])) if st[-1]['steps'] else None,
+             "streamed_chunks": int(st[-1]['streamed_chunks']),
              "lanes_per_member": int(stats.get('lanes_per_member', 1) or 1), "members_flagged": int((res['status'] != 0).sum().item())}
+        if config != 'c2' and not b.args.no_parity:      # (c2: every member is the base member, which parity.golden pins to the reference)
+            b.progress("secondary %s: sample of the benchmarked table against the CPU oracle" % config)
+            d["parity"] = sample_vs_oracle(config, leg.prob, leg.opts, leg.out, leg.host_out, stats, leg.e_local)
         if config == 'c2':
             d["replicas_bit_identical"] = bool((leg.out == leg.out[..., :1]).all().item())
             if leg.host_out is not None:
@@ -604,9 +636,10 @@ def leg_value_weak(b, line, scaling, steps=2):
                                           "same_run_as_value": True, "note": "one GPU: the weak and the strong workload are the same run"}
     if scaling != 'strong':
         return None
-    leg = Leg(b, 'c3', 'weak', CONFIGS['c3']['members'], stream=True)
+    n_members = CONFIGS['c3']['members'] if b.args.secondary_scale is None else max(1, int(round(CONFIGS['c3']['members'] * b.args.secondary_scale)))
+    leg = Leg(b, 'c3', 'weak', n_members, stream=True)
     leg.one_step(leg.host_out)
-    elapsed, res, st = leg.timed(steps, leg.host_out, "value_weak: 100 000 members per GPU")
+    elapsed, res, st = leg.timed(steps, leg.host_out, "value_weak: %d members per GPU" % n_members)
     d = None
     if b.rank == 0:
         import numpy as np
@@ -622,17 +655,34 @@ def leg_value_weak(b, line, scaling, steps=2):
 def parity(args, eng, prob, opts, out, host_out, stats, e_local):
     """Accuracy that goes with the throughput number, two ways: (golden) members through the same kernel and solver settings
     against the reference's own equations integrated by odeint(rtol=atol=1e-12) (tests/golden, recorded from the unmodified
-    reference): the Tarland base member, the six members the step controller was tuned on and 16 members of a held-out draw;
-    (timed_run_sample) seeded members pulled out of the BENCHMARKED table -- slot-ordered, written by the timed kernel, host
-    copy included -- against the CPU oracle."""
-    import numpy as np
-    import torch
+    reference): the Tarland base member, the six members the step controller was tuned on, 16 members of a held-out draw and the
+    ten dry-reach members; (timed_run_sample) seeded members pulled out of the BENCHMARKED table -- slot-ordered, written by the
+    timed kernel, host copy included -- against the CPU oracle."""
     res = {}
     if args.config in ('c2', 'c3'):
         res["golden"] = parity_golden(eng, opts)
+    res["timed_run_sample"] = sample_vs_oracle(args.config, prob, opts, out, host_out, stats, e_local)
+    if args.config == 'c2':
+        res["replicas_bit_identical"] = bool((out == out[..., :1]).all().item())
+    return res
+
+
+# members x leading days of the benchmarked table that go through the CPU oracle (None = all days).  Rows of a day do not depend
+# on later days, so the first two years of C4's 50 are a valid sample of the benchmarked table -- and take seconds, not minutes.
+SAMPLE_SHAPE = {'c2': (8, None), 'c3': (8, None), 'c4': (2, 730), 'c5': (8, None), 'strong_1m': (8, None)}
+
+
+def sample_vs_oracle(config, prob, opts, out, host_out, stats, e_local):
+    """Seeded members pulled out of the BENCHMARKED table (slot order resolved through member_of_slot; the host copy too)
+    against the CPU oracle with the same solver settings -- for the fp32-stage mode its same-arithmetic mirror.  Time-reduced
+    tables (annual sums) are compared with the oracle's daily rows summed the same way."""
+    import ctypes
+    import numpy as np
+    import torch
     from oracle import oracle
+    n_s, n_days = SAMPLE_SHAPE[config]
     rng = np.random.default_rng(12345)
-    n_s = min(8 if args.config != 'c4' else 4, e_local)
+    n_s = min(n_s, e_local)
     members = np.sort(rng.choice(e_local, n_s, replace=False))
     mos = stats.get('member_of_slot')
     if mos is None:
@@ -641,18 +691,22 @@ def parity(args, eng, prob, opts, out, host_out, stats, e_local):
         slot_of = np.empty(e_local, dtype=np.int64)
         slot_of[mos.cpu().numpy().astype(np.int64)] = np.arange(e_local)
     slots = torch.as_tensor(slot_of[members], device=out.device)
-    got = out.index_select(3, slots).cpu().numpy()                            # [ncols, rows, n_or, n_s]
+    D = prob['forcing'].shape[2]
+    if opts.n_periods > 0 or n_days is None or n_days >= D:
+        n_days = D
+    rows = slice(None) if opts.n_periods > 0 else slice(0, n_days)
+    got = out[:, rows].index_select(3, slots).cpu().numpy()                   # [ncols, rows, n_or, n_s]
     # rank 0's block of the ensemble: with strong scaling prob holds every member and rank 0 owns the first ones
     mp = np.ascontiguousarray(prob['member_params'][:, members])
     rp = np.ascontiguousarray(prob['reach_params'][:, :, members])
     o = type(opts)()
-    import ctypes
     ctypes.memmove(ctypes.byref(o), ctypes.byref(opts), ctypes.sizeof(opts))
     o.n_periods = 0
     if o.integrator == 3 and not getattr(oracle, 'HAS_F32_MIRROR', False):
         o.integrator = 2
     t0 = time.perf_counter()
-    ref, ref_status, _ = oracle.run(prob['forcing'], prob['doy'], mp, rp, prob['up_ptr'], prob['up_idx'], o,
+    ref, ref_status, _ = oracle.run(np.ascontiguousarray(prob['forcing'][:, :, :n_days]), np.ascontiguousarray(prob['doy'][:n_days]),
+                                    mp, rp, prob['up_ptr'], prob['up_idx'], o,
                                     out_reaches=prob['out_reaches'], n_threads=min(n_s, os.cpu_count() or 1))
     if opts.n_periods > 0:
         pod = prob['period_of_day']
@@ -663,24 +717,22 @@ def parity(args, eng, prob, opts, out, host_out, stats, e_local):
     rel = np.abs(got - ref) / denom
     rel = np.where(got == ref, 0.0, rel)
     bar = 10.0 * opts.rtol
-    res["timed_run_sample"] = {
-        "members": [int(m) for m in members], "max_rel_err_vs_oracle": float(np.nanmax(rel)), "bar": bar,
-        "what": "%d seeded members of the benchmarked table (slot order resolved through member_of_slot), every requested "
-                "column and row, against the CPU oracle with the same solver settings%s; bar = 10 x rtol" %
-                (n_s, "" if cfg_parity_grade(args) else " (its same-arithmetic mirror of the fp32-stage mode, which is not "
-                                                         "parity-grade: no <= 1e-6 claim against the reference)"),
-        "oracle_seconds": time.perf_counter() - t0}
+    worst = float(np.nanmax(rel))
+    d = {"members": [int(m) for m in members], "max_rel_err_vs_oracle": worst, "bar": bar, "within_bar": bool(worst <= bar),
+         "rows": "all %d rows" % got.shape[1] if n_days == D else "the first %d of %d days" % (n_days, D),
+         "what": "%d seeded members of the benchmarked table (slot order resolved through member_of_slot), every requested "
+                 "column, against the CPU oracle with the same solver settings%s; bar = 10 x rtol" %
+                 (n_s, "" if CONFIGS[config]['parity_grade'] else " (its same-arithmetic mirror of the fp32-stage mode, which is not "
+                                                                    "parity-grade: no <= 1e-6 claim against the reference)"),
+         "oracle_seconds": time.perf_counter() - t0}
     if host_out is not None:
-        res["timed_run_sample"]["host_table_equals_device_table"] = bool(
-            np.array_equal(host_out[:, :, :, slot_of[members]], got, equal_nan=True))
-        if args.config in ('c2', 'c3', 'c5'):          # whole-table check (a device-side compare of a re-uploaded host copy would need 2x HBM)
+        d["host_table_equals_device_table"] = bool(np.array_equal(host_out[:, rows][:, :, :, slot_of[members]], got, equal_nan=True))
+        if config != 'c4':          # whole-table check (a device-side compare of a re-uploaded host copy would need 2x HBM)
             step = max(1, host_out.shape[1] // 64)
             sub = torch.from_numpy(np.ascontiguousarray(host_out[:, ::step])).to(out.device)
-            res["timed_run_sample"]["host_rows_checked"] = int(sub.shape[1])
-            res["timed_run_sample"]["host_rows_equal"] = bool(torch.equal(sub, out[:, ::step]))
-    if args.config == 'c2':
-        res["replicas_bit_identical"] = bool((out == out[..., :1]).all().item())
-    return res
+            d["host_rows_checked"] = int(sub.shape[1])
+            d["host_rows_equal"] = bool(torch.equal(sub, out[:, ::step]))
+    return d
 
 
 def cfg_parity_grade(args):
@@ -723,12 +775,40 @@ def parity_golden(eng, opts):
         res[key] = {"members": [int(x) for x in mm['members']], "worst_member_max_rel_err": float(max(worst)),
                     "per_member": [float(x) for x in worst], "bar": 1e-6, "days": int(g2.shape[1]),
                     "against": "the unmodified reference, odeint rtol=atol=1e-12, member by member (tests/golden/%s)" % fname}
+    if os.path.exists(os.path.join(helpers.GOLDEN, 'dry_members.npz')):
+        mm, tabs = helpers.dry_fixture_problem(solver={k: getattr(opts, k) for k in solver_keys})
+        o3, st3, _ = eng.run(mm['forcing'], mm['doy'], mm['member_params'], mm['reach_params'], mm['up_ptr'], mm['up_idx'], mm['opts'])
+        worst = helpers.dry_worst_per_member(o3.cpu().numpy(), tabs, marshal.OUT_COLUMNS)
+        res["dry_members"] = {"members": [int(x) for x in mm['members']], "worst_member_max_rel_err": float(max(worst)),
+                              "per_member": [float(x) for x in worst], "bar": 1e-6, "days": "two years around each member's worst day",
+                              "against": "the unmodified reference, odeint rtol=atol=1e-12, on a climate with 0.6 x Tarland's precipitation: "
+                                         "reaches that nearly dry up and are wetted again (tests/golden/dry_members.npz)"}
     return res
 
 
-def cpu_baseline(prob, D, S):
+def reference_python_rate():
+    """The reference's own Python/SciPy path as shipped (odeint rtol=0.01), timed on one core of the build container when the golden
+    fixtures were recorded (tests/golden/make_golden.py writes the wall time of every run into series_meta.json): catchment-days/s
+    for the 1-year and the 30-year Tarland runs.  The reference cannot travel to the GPU box, so this is a recorded figure."""
+    try:
+        with open(os.path.join(ROOT, 'tests', 'golden', 'series_meta.json')) as fh:
+            meta = json.load(fh)
+        rates = {}
+        for name, days in (('tarland_1981_2010_dynamic', 10957), ('tarland_2004_dynamic', 366)):
+            rates[name] = days / float(meta[name]['runs']['shipped']['wall_s'])
+        return {"value": [round(min(rates.values()), 1), round(max(rates.values()), 1)], "per_run": {k: round(v, 1) for k, v in rates.items()},
+                "unit": "catchment-days/s per core", "kind": "reference",
+                "sample": "unmodified run_simply_p (odeint rtol=0.01), Tarland 1981-2010 and 2004, 1 core of the build container "
+                          "(wall times recorded in tests/golden/series_meta.json by make_golden.py); the Python reference cannot "
+                          "travel to this node"}
+    except (OSError, KeyError, ValueError) as ex:
+        return {"value": None, "note": "tests/golden/series_meta.json not readable: %s" % ex}
+
+
+def cpu_baseline(prob, D, S, budget_s=20.0):
     """The CPU oracle (a C port of the reference's equations with the same solver; the Python reference cannot travel
-    to this box) timed on the host cores, on a bounded sample of the same workload: all cores used (<= 16) and one core."""
+    to this box) timed on the host cores, on a bounded sample of the same workload: ALL the cores this process may use (the
+    sample is sized by time -- about `budget_s` seconds of wall -- not by a cap on the threads) and one core."""
     import ctypes
     from oracle import oracle
     opts = prob['opts']
@@ -750,21 +830,23 @@ def cpu_baseline(prob, D, S):
         usable = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         usable = os.cpu_count() or 1
-    cores = min(usable, 16)
-    per_member = 0.06 * S * D / 10957.0                     # ~core-seconds per member (measured for the 30-year single reach)
-    n_all = max(cores, min(prob['member_params'].shape[1], int(30.0 / per_member)))
-    n_one = max(1, min(prob['member_params'].shape[1], int(6.0 / per_member)))
-    dt_all = leg(n_all, cores)
-    dt_one = leg(n_one, 1)
-    return {"value": n_all * S * D / dt_all, "unit": "catchment-days/s", "cores": cores, "kind": "port",
-            "sample": "first %d members of the same ensemble, all %d reaches and %d days, %d OpenMP threads, %.1f s wall"
-                      % (n_all, S, D, cores, dt_all),
+    E = prob['member_params'].shape[1]
+    # calibrate the per-member cost on this host with a small one-thread run, then size both samples by time
+    n_cal = max(1, min(E, 8))
+    dt_cal = leg(n_cal, 1)
+    per_member = dt_cal / n_cal                              # core-seconds per member
+    n_one = max(n_cal, min(E, int(6.0 / per_member)))
+    dt_one = leg(n_one, 1) if n_one > n_cal else dt_cal
+    n_all = max(usable, min(E, int(budget_s * usable / per_member)))
+    n_all = min(E, n_all)
+    dt_all = leg(n_all, usable)
+    return {"value": n_all * S * D / dt_all, "unit": "catchment-days/s", "cores": usable, "kind": "port",
+            "usable_cores": usable, "host_cpu_count": os.cpu_count(),
+            "sample": "first %d members of the same ensemble, all %d reaches and %d days, %d OpenMP threads (every core this "
+                      "process may use), %.1f s wall" % (n_all, S, D, usable, dt_all),
             "one_core": {"value": n_one * S * D / dt_one, "cores": 1,
                          "sample": "first %d members, 1 thread, %.1f s wall" % (n_one, dt_one)},
-            "reference_python": {"value": [132, 180], "unit": "catchment-days/s per core", "kind": "reference",
-                                 "sample": "unmodified run_simply_p (odeint rtol=0.01), Tarland 1981-2010 / 2004, 1 core of the "
-                                           "survey container's Xeon 2.1 GHz -- BASELINE.md section 2; the Python reference "
-                                           "cannot travel to this node"}}
+            "reference_python": reference_python_rate()}
 
 
 if __name__ == '__main__':

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIMPLYP_ABI_VERSION 15
+#define SIMPLYP_ABI_VERSION 16
 
 typedef enum {
     SIMPLYP_OK = 0,
@@ -436,6 +436,18 @@ int simplyp_waterbody(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_m
 int simplyp_gof_waterbody(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t wb_mask, const double* wb,
                           const int32_t* member_of_slot, const double* f_tdp,
                           const double* obs, double* gof, simplyp_gof_info* info);
+
+/*
+ * simplyp_eval_units -- the path's scalar device functions on caller-given arguments, one thread per row: how the tests pin the
+ * DEVICE restatements of f_x (model.py:23-37) and discretized_soilP (model.py:39-56 followed by the >= 0 clamps of :696-699 and
+ * conc_TDPs = TDPs / Vs of :702-703) to vectors the unmodified reference functions produced (tests/golden/unit_vectors.npz).
+ *   which = 0   in  device [n][2]  = x, threshold (reld = 0.01)
+ *               out device [n][2]  = f_x as the end-of-day flows evaluate it, f_x as the right-hand side's fused form does
+ *   which = 1   in  device [n][10] = P_netInput, A_catch, Kf, Msoil, EPC0, Qs, Qq, Vs, TDPs, Plab
+ *               out device [n][3]  = TDPs, Plab (clamped at 0 like :696-697), conc_TDPs
+ * Synchronous.  Not on the hot path.
+ */
+int simplyp_eval_units(simplyp_ctx* ctx, int32_t which, int32_t n, const double* in, double* out);
 
 #ifdef __cplusplus
 }

@@ -8,15 +8,19 @@ import subprocess
 
 import numpy as np
 
-from simplyp_amd import abi
+from simplyp_amd import abi, marshal
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libsimplyp_oracle.so')
+# `make -C oracle asan-test` points this at the AddressSanitizer / UBSan build of the same source (never rebuilt from here)
+LIB_OVERRIDE = os.environ.get('SIMPLYP_ORACLE_LIB')
 _lib = None
 HAS_F32_MIRROR = True      # integrator 3 (fp32 stages) has a same-arithmetic mirror: cashkarp_aug_f32_day
 
 
 def build(force=False):
+    if LIB_OVERRIDE:
+        return LIB_OVERRIDE
     inc = os.path.join(os.path.dirname(HERE), 'include')
     srcs = [os.path.join(HERE, 'simplyp_oracle.c'), os.path.join(inc, 'simplyp.h'), os.path.join(inc, 'simplyp_controller.h')]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
@@ -27,9 +31,9 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if not LIB_OVERRIDE and not os.path.exists(LIB_PATH):
             build()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(LIB_OVERRIDE or LIB_PATH)
         L.simplyp_oracle_fx.restype = C.c_double
         L.simplyp_oracle_fx.argtypes = [C.c_double] * 3
         L.simplyp_oracle_run.restype = C.c_int
@@ -74,7 +78,7 @@ def run(forcing, doy, member_params, reach_params, up_ptr, up_idx, opts, forcing
     _, S, E = rp.shape
     dims = abi.Dims(E, S, D, n_sets)
     ncols = bin(opts.out_mask).count('1')
-    if (opts.out_mask >> 25) & 1 and not opts.snow:
+    if opts.out_mask & marshal.MASK_D_SNOW and not opts.snow:
         raise ValueError("column D_snow exists only with opts.snow = 1")
     if out_reaches is not None:
         out_reaches = np.ascontiguousarray(out_reaches, dtype=np.int32)

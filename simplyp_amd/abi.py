@@ -2,7 +2,7 @@
 
 import ctypes as C
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 INTEG_RK4 = 0
 INTEG_CASHKARP = 1

@@ -1149,7 +1149,7 @@ static int gof_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t out_mas
                          waterbody ? (int)SIMPLYP_WB_TDP_FLUX : (int)SIMPLYP_OUT_TDP_FLUX,
                          waterbody ? (int)SIMPLYP_WB_PP_FLUX : (int)SIMPLYP_OUT_PP_FLUX};
     const uint32_t need = (1u << want[0]) | (1u << want[1]) | (1u << want[2]) | (1u << want[3]);
-    if ((out_mask & need) != need || (out_mask & ~(waterbody ? SIMPLYP_WB_MASK_ALL : SIMPLYP_MASK_ALL)) != 0u)
+    if ((out_mask & need) != need || (out_mask & ~(waterbody ? SIMPLYP_WB_MASK_ALL : (SIMPLYP_MASK_ALL | SIMPLYP_MASK_D_SNOW))) != 0u)
         return fail(ctx, SIMPLYP_ERR_ARG, waterbody ? "wb_mask must contain Q_cumecs, Msus_kg/day, TDP_kg/day and PP_kg/day"
                                                     : "out_mask must contain Qr, Msus_kg/day, TDP_kg/day and PP_kg/day");
     const int E = dims->E, S = waterbody ? 1 : dims->S, D = dims->D;
@@ -1307,7 +1307,7 @@ static int spearman_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t ou
     if (!out || !f_tdp || !reach_params || !obs || !rho) return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
     const int want[4] = {SIMPLYP_OUT_QR, SIMPLYP_OUT_MSUS_FLUX, SIMPLYP_OUT_TDP_FLUX, SIMPLYP_OUT_PP_FLUX};
     const uint32_t need = (1u << want[0]) | (1u << want[1]) | (1u << want[2]) | (1u << want[3]);
-    if ((out_mask & need) != need || (out_mask & ~SIMPLYP_MASK_ALL) != 0u)
+    if ((out_mask & need) != need || (out_mask & ~(SIMPLYP_MASK_ALL | SIMPLYP_MASK_D_SNOW)) != 0u)
         return fail(ctx, SIMPLYP_ERR_ARG, "out_mask must contain Qr, Msus_kg/day, TDP_kg/day and PP_kg/day");
     const int E = dims->E, S = dims->S, D = dims->D;
     const int R = out_reaches ? n_out_reaches : S;
@@ -1420,7 +1420,7 @@ static int waterbody_impl(simplyp_ctx* ctx, const simplyp_dims* dims, uint32_t o
     if (!out || !f_tdp || !reach_params || !sum_reaches || !wb) return fail(ctx, SIMPLYP_ERR_ARG, "a required pointer is NULL");
     const uint32_t need = (1u << SIMPLYP_OUT_QR) | (1u << SIMPLYP_OUT_MSUS_FLUX) | (1u << SIMPLYP_OUT_TDP_FLUX) |
                           (1u << SIMPLYP_OUT_PP_FLUX);
-    if ((out_mask & need) != need || (out_mask & ~SIMPLYP_MASK_ALL) != 0u)
+    if ((out_mask & need) != need || (out_mask & ~(SIMPLYP_MASK_ALL | SIMPLYP_MASK_D_SNOW)) != 0u)
         return fail(ctx, SIMPLYP_ERR_ARG, "out_mask must contain Qr, Msus_kg/day, TDP_kg/day and PP_kg/day");
     if ((wb_mask & SIMPLYP_WB_MASK_ALL) == 0u || (wb_mask & ~SIMPLYP_WB_MASK_ALL) != 0u)
         return fail(ctx, SIMPLYP_ERR_ARG, "wb_mask must select 1..%d of the waterbody columns", (int)SIMPLYP_N_WB);
@@ -1518,6 +1518,18 @@ int simplyp_memcpy_d2h(simplyp_ctx* ctx, void* dst, const void* src, int64_t byt
     if (!ctx) return SIMPLYP_ERR_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SIMPLYP_OK;
+}
+
+int simplyp_eval_units(simplyp_ctx* ctx, int32_t which, int32_t n, const double* in, double* out)
+{
+    if (!ctx) return SIMPLYP_ERR_ARG;
+    if (which < 0 || which > 1 || n < 0 || (n > 0 && (!in || !out))) return fail(ctx, SIMPLYP_ERR_ARG, "simplyp_eval_units: bad arguments");
+    if (n == 0) return SIMPLYP_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(simplyp::eval_units_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (int)which, (int)n, in, out);
+    HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SIMPLYP_OK;
 }

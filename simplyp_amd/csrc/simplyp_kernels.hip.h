@@ -1167,8 +1167,9 @@ __device__ __forceinline__ int nc_type_of(double f_NC_A, double f_NC_S)     // m
 // (by b, by Vs, by b*Vs) share two reciprocals, 1/Vs and 1/b (sp_rcp: hardware seed + two Newton steps, correctly rounded on
 // every sample tried, tools/micro/rcp_accuracy.hip): a * (1/b) instead of a / b differs in the last bit at most -- eleven orders
 // of magnitude below the parity bar -- and an IEEE division is ~12 instructions on this chip, a quarter of the day-boundary
-// code before round 3.  (Vs == 0 never happens with water in the soil box; the reference leaves NaN in conc_TDPs there, here
-// the reciprocal does, and the member is flagged.)
+// code before round 3.  Vs == 0 (never met with water in the soil box, but the reference defines it): b = inf there, so the
+// reference gets TDPs = 0 + (TDPs - 0) * 0, sorp = 0 (:50), Plab unchanged and conc_TDPs = 0/0 = NaN; the reciprocals of 0 are
+// NaN after their Newton steps, so that case is one select on TDPs (sorp is guarded as in the reference; conc = TDPs * NaN).
 struct SoilPRate { double rVs, b; };
 
 __device__ __forceinline__ SoilPRate soil_p_rate(double KfMsoil, double Qs, double Qq, double Vs)
@@ -1187,6 +1188,7 @@ __device__ __forceinline__ void soil_p_update(double aP, double KfMsoil, double 
     const double rb = sp_rcp(r.b);
     const double aob = a * rb;
     double T = aob + (TDPs - aob) * emb;                                          // :44
+    T = (Vs == 0.0) ? (TDPs - 0.0) * 0.0 : T;                                     // b = inf: a/b = 0, exp(-b) = 0
     double sorp = 0.0;
     const double aobv = aob * r.rVs;                                              // a / (b Vs) = a / b0, :47
     if (Vs > 0.0)                                                                 // :50
@@ -1227,9 +1229,15 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
 
     const int set = a.forcing_of_member ? a.forcing_of_member[pe] : 0;
     const bool shared_forcing = (a.forcing_of_member == nullptr);
-    const double* Pser = a.forcing + (size_t)set * (SNOW ? 3 : 2) * Dst;        // P, or Precipitation when SNOW
-    const double* Eser = Pser + Dst;
-    const double* Tser = Eser + Dst;                                            // T_air (SNOW only)
+    // Rows of this member's forcing set: P (Precipitation when SNOW), PET, T_air (SNOW only).  The set may differ per lane, so
+    // these are per-lane 64-bit pointers; left to the compiler they are hoisted out of the day loop and held in 6 VGPRs across the
+    // attempt loop (the snow instantiation of the chain kernel then spilled 20 B per lane to scratch).  Formed from the set number
+    // where they are used instead -- once per 256-day tile, or per day for per-member forcing -- behind an opaque copy of it.
+#define SP_FORCING_ROWS \
+    int set_o = set; asm volatile("" : "+v"(set_o)); \
+    const double* Pser = a.forcing + (size_t)set_o * (SNOW ? 3 : 2) * Dst; \
+    const double* Eser = Pser + Dst; \
+    const double* Tser = Eser + Dst; (void)Tser;
 
     // ---- member constants (model.py:349-361, 377-390) ----
     const double fc = MPv(SIMPLYP_PM_FC), f_quick = MPv(SIMPLYP_PM_F_QUICK), alpha = MPv(SIMPLYP_PM_ALPHA);
@@ -1368,6 +1376,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
             const int nd = min(TILE_D, d_end - d0);
 
             if (shared_forcing) {
+                SP_FORCING_ROWS
                 __syncthreads();
                 for (int i = lane; i < nd; i += WAVE) { s_P[i] = Pser[d0 + i]; s_E[i] = Eser[d0 + i]; }
                 if (SNOW) for (int i = lane; i < nd; i += WAVE) s_T[i] = Tser[d0 + i];
@@ -1376,10 +1385,15 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
             }
             for (int dd = 0; dd < nd; ++dd) {
                 const int d = d0 + dd;
-                double P = shared_forcing ? s_P[dd] : Pser[d];                                    // :497
+                double P, PET, T_air = 0.0;
+                if (shared_forcing) {
+                    P = s_P[dd]; PET = s_E[dd]; if (SNOW) T_air = s_T[dd];                        // :497-498
+                } else {
+                    SP_FORCING_ROWS
+                    P = Pser[d]; PET = Eser[d]; if (SNOW) T_air = Tser[d];
+                }
                 if (SNOW) {
                     // snow_hydrol_inputs (inputs.py:183-208) for this member: P so far is the day's precipitation
-                    const double T_air = shared_forcing ? s_T[dd] : Tser[d];
                     const double P_snow = (T_air < 0.0) ? P : 0.0;                                // :183-184
                     const double P_rain = P - P_snow;                                             // :187
                     double P_melt = MPv(SIMPLYP_PM_F_DDSM) * (T_air - 0);                         // :190
@@ -1388,7 +1402,6 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     D_snow = D_snow + P_snow - P_melt;                                            // :200, :205
                     P = P_rain + P_melt;                                                          // :208
                 }
-                const double PET = shared_forcing ? s_E[dd] : Eser[d];                            // :498
                 const double Qq = f_quick * P;                                                    // :501
 
                 // upstream inputs (:508-544): same-day daily means / fluxes of the reaches above
@@ -1600,6 +1613,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
     }
 #undef MPv
 #undef RPv
+#undef SP_FORCING_ROWS
 
     // ---- per-wave solver statistics and member status ----
     if (!writer) { n_rhs = 0; n_steps = 0; n_rej = 0; }
@@ -1807,6 +1821,34 @@ __global__ void gather_columns_kernel(const T* __restrict__ src, T* __restrict__
     if (i >= E) return;
     const int e = perm[i];
     for (int r = blockIdx.y; r < rows; r += gridDim.y) dst[(size_t)r * E + i] = src[(size_t)r * E + e];
+}
+
+// The scalar device functions of the path on caller-given arguments (simplyp_eval_units): what lets the tests pin the DEVICE
+// restatements of f_x (model.py:23-37) and discretized_soilP (:39-56, with the clamps of :696-699 and the concentration of
+// :702-703) to the vectors the unmodified reference functions produced, Vs == 0 included.
+//   which 0: in [n][2] = x, threshold           -> out [n][2] = f_x by gate() (end-of-day flows), f_x by the fused form of SysAug::f
+//   which 1: in [n][10] = P_netInput, A_catch, Kf, Msoil, EPC0, Qs, Qq, Vs, TDPs, Plab  -> out [n][3] = TDPs, Plab, conc_TDPs
+__global__ void eval_units_kernel(int which, int n, const double* __restrict__ in, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0) {
+        const double x = in[2 * i], th = in[2 * i + 1];
+        const double inv_d = (th * 0.01 > 0.0) ? 1.0 / (0.01 * th) : 1.0e300;      // threshold 0 -> plain step (run_slot: c.inv_dg)
+        out[2 * i] = gate(x - th, inv_d);
+        double s = __builtin_fma(x, inv_d, -th * inv_d);                           // SysAug::f: s = fma(Vs, inv_d, s0), s0 = -fc inv_d
+        s = __builtin_fmin(__builtin_fmax(s, 0.0), 1.0);
+        out[2 * i + 1] = (s * s) * __builtin_fma(-2.0, s, 3.0);
+    } else {
+        const double* a = in + 10 * (size_t)i;
+        const double aP = a[0] * a[1] * 100.0 / 365.;                              // run_slot: aP_A
+        const double KfMsoil = a[2] * a[3];
+        const SoilPRate r = soil_p_rate(KfMsoil, a[5], a[6], a[7]);
+        const double emb = sp_exp(__builtin_fmax(-r.b, -700.0));
+        double TDPs = a[8], Plab = a[9], conc;
+        soil_p_update(aP, KfMsoil, a[4], a[7], r, emb, TDPs, Plab, conc);
+        out[3 * i] = TDPs; out[3 * i + 1] = Plab; out[3 * i + 2] = conc;
+    }
 }
 
 }  // namespace simplyp

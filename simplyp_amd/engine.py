@@ -26,7 +26,7 @@ ABI_SYMBOLS = ['simplyp_abi_version', 'simplyp_device_count', 'simplyp_ctx_creat
                'simplyp_last_error', 'simplyp_ctx_set_stream', 'simplyp_out_bytes', 'simplyp_run',
                'simplyp_run_async', 'simplyp_sync', 'simplyp_plan', 'simplyp_host_alloc', 'simplyp_host_free',
                'simplyp_device_alloc', 'simplyp_device_free', 'simplyp_memcpy_h2d', 'simplyp_memcpy_d2h', 'simplyp_gof',
-               'simplyp_stream_out', 'simplyp_waterbody', 'simplyp_gof_waterbody', 'simplyp_gof_spearman']
+               'simplyp_stream_out', 'simplyp_waterbody', 'simplyp_gof_waterbody', 'simplyp_gof_spearman', 'simplyp_eval_units']
 
 _lib = None
 
@@ -110,6 +110,8 @@ def lib():
     L.simplyp_device_alloc.argtypes = [vp, C.c_int64]
     L.simplyp_device_free.restype = None
     L.simplyp_device_free.argtypes = [vp, vp]
+    L.simplyp_eval_units.restype = C.c_int
+    L.simplyp_eval_units.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     for name in ('simplyp_memcpy_h2d', 'simplyp_memcpy_d2h'):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp, vp, vp, C.c_int64]
@@ -363,6 +365,21 @@ class Engine(object):
         return out, status, sd
 
 
+    def eval_units(self, which, rows):
+        """The path's scalar device functions on given arguments (``simplyp_eval_units``): ``which`` = 'f_x' (rows [n, 2] =
+        x, threshold -> [n, 2]: the gate as the end-of-day flows and as the right-hand side evaluate it) or 'soilp' (rows
+        [n, 10] = the arguments of the reference's discretized_soilP -> [n, 3] = TDPs, Plab, conc_TDPs)."""
+        torch = self.torch
+        w, k_in, k_out = {'f_x': (0, 2, 2), 'soilp': (1, 10, 3)}[which]
+        a = self.to_device(np.ascontiguousarray(rows, dtype=np.float64), torch.float64)
+        if a.dim() != 2 or a.shape[1] != k_in:
+            raise ValueError("%s takes rows of %d values" % (which, k_in))
+        out = torch.empty((a.shape[0], k_out), dtype=torch.float64, device=self.tdev)
+        with torch.cuda.device(self.tdev):
+            self._bind_stream()
+            self._check(lib().simplyp_eval_units(self._h, w, a.shape[0], a.data_ptr(), out.data_ptr()), 'simplyp_eval_units')
+        return out.cpu().numpy()
+
     def gof(self, out, out_mask, obs, f_tdp, reach_params, out_reaches=None, member_of_slot=None, spearman=False):
         """Per-member goodness-of-fit statistics (the reference's ``goodness_of_fit_stats``,
         visualise_results.py:387-474, without Spearman's r) of the daily table ``out`` of a previous ``run``.
@@ -489,8 +506,10 @@ class Engine(object):
 _engines = {}
 
 
-def get_engine(device=0):
-    """Process-wide engine per device (contexts hold grow-only device scratch)."""
-    if device not in _engines:
-        _engines[device] = Engine(device)
-    return _engines[device]
+def get_engine(device=0, replica=0):
+    """Process-wide engine per device (contexts hold grow-only device scratch).  ``replica`` > 0 gives a further context on the
+    same device (contexts are not re-entrant: two host threads that drive one GPU need one each)."""
+    key = (int(device), int(replica))
+    if key not in _engines:
+        _engines[key] = Engine(device)
+    return _engines[key]

@@ -152,7 +152,8 @@ def _output_dict(stats, status, solver):
     integrates here, so the engine's own statistics are returned, and the keys a caller of the reference could have read are
     kept as aliases with the same types: 'nfe' (right-hand-side evaluations), 'nst' (accepted steps), 'nje' (Jacobian
     evaluations: none, the pair is explicit) as one-element int32 arrays -- totals over the whole run, not the last day's
-    call --, 'mused' (1 = non-stiff method) and 'message' ('Integration successful.' unless the member was flagged)."""
+    call; saturating at 2**31 - 1 (a large network exceeds int32: the exact totals are under 'rhs_evals' / 'steps') --,
+    'mused' (1 = non-stiff method) and 'message' ('Integration successful.' unless the member was flagged)."""
     msg = 'Integration successful.'
     if status & abi.STATUS_NONFINITE:
         msg = 'Non-finite state met (member status %d); results from that day on are NaN.' % status
@@ -160,8 +161,9 @@ def _output_dict(stats, status, solver):
         msg = 'Excess work done on a day (max_steps attempts; member status %d).' % status
     d = dict(stats, member_status=status, solver=dict(abi.DEFAULT_SOLVER, **(solver or {})), engine='MI355X batched engine',
              message=msg)
-    d['nfe'] = np.array([stats['rhs_evals']], dtype=np.int32)
-    d['nst'] = np.array([stats['steps']], dtype=np.int32)
+    i32max = np.iinfo(np.int32).max
+    d['nfe'] = np.array([min(int(stats['rhs_evals']), i32max)], dtype=np.int32)
+    d['nst'] = np.array([min(int(stats['steps']), i32max)], dtype=np.int32)
     d['nje'] = np.array([0], dtype=np.int32)
     d['mused'] = np.array([1], dtype=np.int32)
     return d
@@ -274,7 +276,7 @@ def _host_table(shape, pin):
 def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options, overrides=None, n_members=None,
                           outputs=None, out_reaches=None, step_len=1., solver=None, device=0, to_host=True,
                           reduce=None, obs_dict=None, keep_daily=True, snow_in_kernel=None, forcing_of_member=None,
-                          waterbody=None, waterbody_obs=None, spearman=False):
+                          waterbody=None, waterbody_obs=None, spearman=False, devices=None):
     """Run an ensemble of parameter sets through the engine in one call.
 
     ``overrides``: dict name -> array[E] (member parameters, see ``marshal.PM_NAMES``) or
@@ -306,6 +308,16 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
     four flux columns / the summed reaches to the outputs when missing.  ``waterbody_obs``: DataFrame of observations
     at the waterbody's inflow (columns among Q, SS, TDP, PP, TP, SRP): the members' goodness-of-fit table of the summed
     series under ``['waterbody']['gof']``.
+
+    ``devices``: a list of GPU ids, e.g. ``[0, 1, ..., 7]`` -- the ensemble is split into contiguous member blocks
+    (``ensemble.shard_bounds``), one per entry, and the blocks run at the same time from this one process: one engine context and
+    one host thread per entry (ctypes releases the GIL), every block's table streamed over its own GPU's PCIe link, the
+    goodness-of-fit / waterbody reductions done where the block's table lies.  No process group, no ``torchrun``: a notebook call
+    (SURVEY.md section 8b's ``devices=`` argument; what the reference's only ensemble caller did with an ``IPython.parallel`` pool,
+    Development/2016/MCMC.ipynb:30-31, :379-385).  Members are independent, so every table is bit-identical to the one-device
+    run's.  An id may repeat (``[0, 0]``: two contexts on one GPU).  ``device`` is ignored when ``devices`` is given.
+    ``stats`` then holds sums / maxima over the blocks and the per-block dicts under ``'per_device'``; with ``to_host=False``
+    ``data`` is the list of the blocks' device tensors (member axis split as ``stats['bounds']``).
 
     Returns ``dict(columns, reaches, data[n_cols, D or n_periods, n_reaches, E], status[E], stats)``; ``data``
     and ``status`` are numpy arrays, or device tensors when ``to_host`` is False.
@@ -390,49 +402,126 @@ def run_simply_p_ensemble(met_df, p_struc, p_SU, p_LU, p_SC, p, dynamic_options,
                         n_periods=0 if periods is None else len(periods), snow=snow_in_kernel)
     oreach = None if out_reaches is None else [scs.index(int(r)) for r in out_reaches]
 
-    eng = engine.get_engine(device)
-    rp_d = eng.to_device(rp)
-    # to_host: the table is delivered into page-locked host memory while the kernel runs (simplyp_stream_out) -- unless the
-    # caller only wants the statistics (keep_daily=False)
-    host_out = None
-    if to_host and (keep_daily or obs_dict is None):
-        n_or_ = len(scs) if oreach is None else len(oreach)
-        rows_ = len(met_df) if periods is None else len(periods)
-        host_out = _host_table((bin(mask).count('1'), rows_, n_or_, E), pin)
-    out_d, status_d, stats = eng.run(forcing, doy, mp, rp_d, up_ptr, up_idx, opts, out_reaches=oreach,
-                                     period_of_day=period_of_day, forcing_of_member=forcing_of_member, host_out=host_out)
-    marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)
     reaches = scs if out_reaches is None else list(out_reaches)
-    res = dict(columns=marshal.columns_of_mask(mask), reaches=reaches, periods=periods, stats=stats,
-               status=status_d.cpu().numpy() if to_host else status_d)
-    if obs_dict is not None:
+    n_or_ = len(scs) if oreach is None else len(oreach)
+    rows_ = len(met_df) if periods is None else len(periods)
+    ncols_ = bin(mask).count('1')
+    want_host_table = to_host and (keep_daily or obs_dict is None)
+    obs = wobs = None
+    if obs_dict is not None or (wb_reaches is not None and len(wb_reaches) > 1 and waterbody_obs is not None):
         from . import visualise_results as vr
-        obs = vr.observation_array(obs_dict, reaches, met_df.index)
-        gof_d, info = eng.gof(out_d, mask, obs, p['f_TDP'] if f_tdp is None else f_tdp, rp_d, out_reaches=oreach,
-                              member_of_slot=stats.get('member_of_slot') if opts.out_slot_order else None, spearman=spearman)
-        rho = info.pop('spearman', None)
-        res['gof'] = dict(stats=list(abi.GOF_STATS), variables=list(abi.GOF_VARS), info=info,
-                          data=gof_d.cpu().numpy() if to_host else gof_d)
-        if rho is not None:       # Spearman's r [6, n_reaches, E]: the rank statistic of the reference's table (:444-445)
-            res['gof']['spearman'] = rho.cpu().numpy() if to_host else rho
-    if wb_reaches is not None:
-        if len(wb_reaches) > 1:
-            mos = stats.get('member_of_slot') if opts.out_slot_order else None
-            ft = p['f_TDP'] if f_tdp is None else f_tdp
+        if obs_dict is not None:
+            obs = vr.observation_array(obs_dict, reaches, met_df.index)
+        if wb_reaches is not None and len(wb_reaches) > 1 and waterbody_obs is not None:
+            wobs = vr.observation_array({0: waterbody_obs}, [0], met_df.index)[0]
+    ft_all = p['f_TDP'] if f_tdp is None else f_tdp
+
+    def block_pass(eng, lo, hi):
+        """Members [lo, hi) on one engine context: the run, then the reductions that want the table where it lies."""
+        whole = (lo == 0 and hi == E)
+        mp_b = mp if whole else np.ascontiguousarray(mp[:, lo:hi])
+        rp_b = rp if whole else np.ascontiguousarray(rp[:, :, lo:hi])
+        fom_b = None if forcing_of_member is None else np.ascontiguousarray(forcing_of_member[lo:hi])
+        ft = ft_all if np.ndim(ft_all) == 0 else np.ascontiguousarray(np.asarray(ft_all, dtype=np.float64)[lo:hi])
+        rp_d = eng.to_device(rp_b)
+        # to_host: the table is delivered into page-locked host memory while the kernel runs (simplyp_stream_out) -- unless the
+        # caller only wants the statistics (keep_daily=False)
+        host_out = _host_table((ncols_, rows_, n_or_, hi - lo), pin) if want_host_table else None
+        out_d, status_d, stats = eng.run(forcing, doy, mp_b, rp_d, up_ptr, up_idx, opts, out_reaches=oreach,
+                                         period_of_day=period_of_day, forcing_of_member=fom_b, host_out=host_out)
+        part = dict(stats=stats, status=status_d.cpu().numpy() if to_host else status_d, host_out=host_out)
+        mos = stats.get('member_of_slot') if opts.out_slot_order else None
+        if obs is not None:
+            gof_d, info = eng.gof(out_d, mask, obs, ft, rp_d, out_reaches=oreach, member_of_slot=mos, spearman=spearman)
+            rho = info.pop('spearman', None)
+            part['gof'] = (gof_d.cpu().numpy() if to_host else gof_d, info,
+                           None if rho is None else (rho.cpu().numpy() if to_host else rho))
+        if wb_reaches is not None and len(wb_reaches) > 1:
             wb_d, winfo = eng.waterbody(out_d, mask, [scs.index(r) for r in wb_reaches], ft, rp_d, out_reaches=oreach,
                                         member_of_slot=mos)
-            res['waterbody'] = dict(columns=winfo['columns'], reaches=wb_reaches, info=winfo,
-                                    data=wb_d.cpu().numpy() if to_host else wb_d)
-            if waterbody_obs is not None:
-                from . import visualise_results as vr
-                wobs = vr.observation_array({0: waterbody_obs}, [0], met_df.index)[0]
+            part['wb'] = (wb_d.cpu().numpy() if to_host else wb_d, winfo)
+            if wobs is not None:
                 g_d, ginfo = eng.gof_waterbody(wb_d, winfo['columns'], wobs, ft, member_of_slot=mos)
-                res['waterbody']['gof'] = dict(stats=list(abi.GOF_STATS), variables=list(abi.GOF_VARS), info=ginfo,
-                                               data=g_d.cpu().numpy() if to_host else g_d)
+                part['wb_gof'] = (g_d.cpu().numpy() if to_host else g_d, ginfo)
+        part['out_d'] = None if (obs_dict is not None and not keep_daily) else out_d
+        return part
+
+    if devices is None:
+        parts, bounds = [block_pass(engine.get_engine(device), 0, E)], [(0, E)]
+    else:
+        from . import ensemble
+        devs = [int(d) for d in devices]
+        if not devs:
+            raise ValueError("devices must name at least one GPU")
+        if opts.out_slot_order:
+            raise ValueError("devices=[...] returns tables in member order: solver['out_slot_order'] must stay 0")
+        bounds = [ensemble.shard_bounds(E, len(devs), r) for r in range(len(devs))]
+        # one context per list entry (a repeated id gets a context of its own: contexts are not re-entrant)
+        engs = [engine.get_engine(d, replica=devs[:r].count(d)) for r, d in enumerate(devs)]
+        live = [(eng_, lo, hi) for eng_, (lo, hi) in zip(engs, bounds) if hi > lo]
+        bounds = [(lo, hi) for _, lo, hi in live]
+        if len(live) == 1:
+            parts = [block_pass(*live[0])]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(live)) as pool:
+                parts = list(pool.map(lambda a_: block_pass(*a_), live))
+    marshal.epilogue_mutations(p_SU, p_LU, p_SC, p)
+
+    cat = (lambda xs: np.concatenate(xs, axis=-1)) if to_host else (lambda xs: xs[0] if len(xs) == 1 else _torch_cat(xs))
+    if len(parts) == 1:
+        stats = parts[0]['stats']
+    else:
+        per = [pt['stats'] for pt in parts]
+        stats = {k: sum(d_[k] for d_ in per) for k in ('rhs_evals', 'steps', 'rejected', 'n_launches', 'streamed_chunks',
+                                                         'queue_waits')}
+        stats.update({k: max(d_[k] for d_ in per) for k in ('kernel_ms', 'pilot_ms', 'wall_ms', 'd2h_tail_ms',
+                                                            'queue_longest_wait_polls', 'queue_longest_stall_polls')})
+        for k in ('balanced', 'queued', 'lanes_per_wave', 'lanes_per_member'):
+            stats[k] = per[0][k]
+        stats['simt_efficiency'] = float(np.mean([d_['simt_efficiency'] for d_ in per]))
+        stats['per_device'] = [dict(d_, device=int(dv), members=[int(lo), int(hi)])
+                               for d_, dv, (lo, hi) in zip(per, [e_.device for e_, _, _ in live], bounds)]
+    stats['bounds'] = [[int(lo), int(hi)] for lo, hi in bounds]
+    res = dict(columns=marshal.columns_of_mask(mask), reaches=reaches, periods=periods, stats=stats,
+               status=cat([pt['status'] for pt in parts]))
+    if obs is not None:
+        res['gof'] = dict(stats=list(abi.GOF_STATS), variables=list(abi.GOF_VARS), info=parts[0]['gof'][1],
+                          data=cat([pt['gof'][0] for pt in parts]))
+        if parts[0]['gof'][2] is not None:       # Spearman's r [6, n_reaches, E]: the rank statistic of the reference's table (:444-445)
+            res['gof']['spearman'] = cat([pt['gof'][2] for pt in parts])
+    if wb_reaches is not None:
+        if len(wb_reaches) > 1:
+            winfo = parts[0]['wb'][1]
+            res['waterbody'] = dict(columns=winfo['columns'], reaches=wb_reaches, info=winfo, data=cat([pt['wb'][0] for pt in parts]))
+            if wobs is not None:
+                res['waterbody']['gof'] = dict(stats=list(abi.GOF_STATS), variables=list(abi.GOF_VARS), info=parts[0]['wb_gof'][1],
+                                               data=cat([pt['wb_gof'][0] for pt in parts]))
         else:
             print('One or fewer reaches were selected to be included in the sum, check your reach structure parameters')   # :896
             res['waterbody'] = None
     if obs_dict is not None and not keep_daily:
-        out_d = None
-    res['data'] = None if out_d is None else (host_out if to_host else out_d)
+        res['data'] = None
+    elif not to_host:
+        res['data'] = parts[0]['out_d'] if len(parts) == 1 else [pt['out_d'] for pt in parts]
+    elif len(parts) == 1:
+        res['data'] = parts[0]['host_out']
+    else:
+        # one table in member order: every block's page-locked table is copied into its member range (one host thread per
+        # block; numpy releases the GIL in the copy), block by block freed
+        data = np.empty((ncols_, rows_, n_or_, E), dtype=np.float64)
+
+        def place(k):
+            lo, hi = bounds[k]
+            data[..., lo:hi] = parts[k]['host_out']
+            parts[k]['host_out'] = None
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(parts)) as pool:
+            list(pool.map(place, range(len(parts))))
+        res['data'] = data
     return res
+
+
+def _torch_cat(xs):
+    import torch
+    return torch.cat([x.to(xs[0].device) for x in xs], dim=-1)

@@ -64,6 +64,23 @@ def monte_carlo_overrides(p, p_LU, n_members, seed=C3_SEED):
     return over
 
 
+WIDE_NAMES = ('T_s_A', 'T_s_S', 'T_g', 'a_Q', 'E_M', 'f_quick')
+
+
+def widen_overrides(over, p, p_LU, n_members, seed, wide):
+    """A wider parameter distribution than BASELINE C3's: the soil, groundwater and reach time scales / rates of `over`
+    (``monte_carlo_overrides``; parameters it does not draw start from the workbook value) times a further log-uniform factor in
+    [1/wide, wide], drawn with ``default_rng(seed + 2000)`` in the order of ``WIDE_NAMES`` -- the draw of
+    tools/probe_tolerance.py's SIMPLYP_PROBE_WIDE and of the dry-reach fixture (tests/golden/make_golden.py --only dry)."""
+    rng = np.random.default_rng(seed + 2000)
+    base = marshal.member_params(p, p_LU, 1)[:, 0]
+    out = dict(over)
+    for name in WIDE_NAMES:
+        cur = np.asarray(out[name], dtype=float) if name in out else np.full(int(n_members), base[marshal.PM_NAMES.index(name)])
+        out[name] = cur * np.exp(rng.uniform(-np.log(wide), np.log(wide), int(n_members)))
+    return out
+
+
 def c3_problem(n_members, st_dt='1981-01-01', end_dt='2010-12-31', seed=C3_SEED, solver=None,
                out_mask=marshal.MASK_REACH5, replicated=False):
     """Arrays + options of the Tarland Monte-Carlo ensemble (BASELINE config C3; `replicated=True` gives

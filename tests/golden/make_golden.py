@@ -15,7 +15,7 @@ How the reference is driven:
     either as shipped (rtol=0.01, default atol, mxstep=5000) or at rtol=atol=1e-12
     ("tight": the converged solution of the reference's own equations = the parity oracle).
 
-Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout]
+Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout|dry]
 """
 
 import argparse
@@ -105,8 +105,10 @@ class OdeintSwitch(object):
             out = scipy.integrate.odeint(func, y0, t, args=args, full_output=full_output,
                                          rtol=rtol, mxstep=mxstep, **kw)
         else:
+            # a pair (rtol, atol) runs the convergence check of the dry-reach fixture (--only dry-check)
+            rt, at = self.tight if isinstance(self.tight, tuple) else (self.tight, self.tight)
             out = scipy.integrate.odeint(func, y0, t, args=args, full_output=full_output,
-                                         rtol=self.tight, atol=self.tight, mxstep=100000, **kw)
+                                         rtol=rt, atol=at, mxstep=100000, **kw)
         if full_output:
             self.nfe += int(out[1]['nfe'][-1])
             self.calls += 1
@@ -216,6 +218,9 @@ def run_reference(mods, switch, sc, tight):
     met = sc['met'].copy()
     with contextlib.redirect_stdout(io.StringIO()):
         met = inputs.snow_hydrol_inputs(p['D_snow_0'], p['f_DDSM'], met)
+    if sc.get('pscale', 1.0) != 1.0:      # another climate: hydrological input x pscale, PET / pscale (tools/probe_tolerance.py SIMPLYP_PROBE_PSCALE)
+        met['P'] = met['P'] * sc['pscale']
+        met['PET'] = met['PET'] / sc['pscale']
     dyn = pd.Series(dict(sc['dyn'], Dynamic_effluent_inputs='n', Dynamic_terrestrialP_inputs='n'))
     switch.tight, switch.nfe, switch.calls = tight, 0, 0
     t0 = time.time()
@@ -364,15 +369,20 @@ REACH_COLS = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_E
 
 def _member_worker(job):
     """One member of the C3 distribution through the unmodified reference at rtol=atol=1e-12 (own process: the reference
-    is single-threaded Python).  job = (seed, n_draw, member, st_dt, end_dt)."""
-    seed, n_draw, member, st_dt, end_dt = job
+    is single-threaded Python).  job = (seed, n_draw, member, st_dt, end_dt[, pscale, wide]): pscale = another climate
+    (run_reference), wide = the draws of the time constants and rates widened as tools/probe_tolerance.py SIMPLYP_PROBE_WIDE does."""
+    seed, n_draw, member, st_dt, end_dt = job[:5]
+    pscale, wide = (job[5], job[6]) if len(job) > 5 else (1.0, 1.0)
+    tight = job[7] if len(job) > 7 else 1e-12
     from simplyp_amd import synthetic, marshal
     mods = load_reference()
     switch = OdeintSwitch()
     mods['model'].odeint = switch
     p_SU, p, p_LU, p_SC, p_struc, met = tarland_inputs(st_dt, end_dt)
     over = synthetic.monte_carlo_overrides(p, p_LU, n_draw, seed=seed)
-    sc = dict(p_SU=p_SU, p=p.copy(), p_LU=p_LU.copy(), p_SC=p_SC, p_struc=p_struc, met=met,
+    if wide != 1.0:
+        over = synthetic.widen_overrides(over, p, p_LU, n_draw, seed, wide)
+    sc = dict(p_SU=p_SU, p=p.copy(), p_LU=p_LU.copy(), p_SC=p_SC, p_struc=p_struc, met=met, pscale=pscale,
               dyn=dict(Dynamic_EPC0='y', Dynamic_erodibility='n'))
     for name in over:
         src = dict(marshal.PM_SPEC)[name]
@@ -380,9 +390,9 @@ def _member_worker(job):
             sc['p'][src[1]] = float(over[name][member])
         else:
             sc['p_LU'].loc[src[1], src[2]] = float(over[name][member])
-    r = run_reference(mods, switch, sc, 1e-12)
+    r = run_reference(mods, switch, sc, tight)
     R = r['df_R'][1]
-    print('seed %d member %d: wall %.1f s  nfe/day %.1f' % (seed, member, r['wall'], r['nfe_per_day']), flush=True)
+    print('seed %d member %d (tolerances %s): wall %.1f s  nfe/day %.1f' % (seed, member, tight, r['wall'], r['nfe_per_day']), flush=True)
     return (member, R[REACH_COLS].to_numpy(dtype=float), {k: float(over[k][member]) for k in sorted(over)})
 
 
@@ -402,6 +412,83 @@ def members_fixture(fname, seed, n_draw, members, st_dt, end_dt, n_proc):
     print(fname, 'written')
 
 
+# The dry-reach regime (round 4): members of two 100 000-member draws on a climate with 0.6 x Tarland's precipitation and 1/0.6 x its
+# PET whose reach nearly dries up (Qg_min ~ 0) and is wetted again -- where the flow equation dQr/dt = (I - Qr) cQ Qr**b_Q
+# (model.py:127-130) amplifies errors, the regime the step controller's expansive-reach rule (include/simplyp_controller.h) was written
+# for.  (seed, wide, member, worst day): the six members with the largest error of the default solver against the converged one among
+# the 256 with the smallest Qg_min of draw C3_SEED + 12 (tests/test_gpu_parity.py::dry_climate_members), and the four worst of draw
+# C3_SEED + 21 with the time constants widened x/÷ 2 (the 7.2e-7 case of profiles/r03_tolerance/heldout_wide_x2_dry.log: member 12935).
+# Each runs from 1981-01-01 to one year past its worst day; the fixture keeps the two years around that day.
+# Tolerances: odeint rtol 1e-12, atol 1e-15.  The other fixtures' rtol = atol = 1e-12 is NOT converged here in the relative sense: these
+# reaches hold Vr ~ 1e-4 mm and suspended sediment ~ 1e-5 kg, Vr has no restoring term (model.py:131), and an ABSOLUTE tolerance of 1e-12
+# per step lets it drift by ~1e-9 over 25 years -- 3e-5 of its value, which every mass flux (x Qr / Vr) inherits.  Measured with
+# --only dry-check (profiles/r04_dry/reference_convergence.log): rtol = atol = 1e-10 against 1e-12 differ by up to 3.9e-3 on these
+# members, (1e-12, 1e-12) against (1e-12, 1e-15) by up to 8.6e-5 -- and the latter difference is, to two digits, the distance between
+# the (1e-12, 1e-12) tables and the engine's own converged solution.
+DRY_PSCALE = 0.6
+DRY_TOLS = (1e-12, 1e-15)
+DRY_MEMBERS = [(12, 1.0, 84724, 2500), (12, 1.0, 94964, 4301), (12, 1.0, 94794, 2692), (12, 1.0, 82156, 2919),
+               (12, 1.0, 74937, 1458), (12, 1.0, 10261, 4885),
+               (21, 2.0, 12935, 6148), (21, 2.0, 73126, 2500), (21, 2.0, 68099, 7141), (21, 2.0, 24911, 9775)]
+
+
+def dry_fixture(n_proc):
+    import multiprocessing as mp
+    from simplyp_amd import synthetic
+    days = pd.date_range('1981-01-01', '2010-12-31')
+    jobs, windows = [], []
+    for dseed, wide, member, worst in DRY_MEMBERS:
+        hi = min(len(days), worst + 366)
+        lo = max(0, worst - 365)
+        jobs.append((synthetic.C3_SEED + dseed, 100000, member, '1981-01-01', days[hi - 1].strftime('%Y-%m-%d'), DRY_PSCALE, wide, DRY_TOLS))
+        windows.append((lo, hi))
+    order = np.argsort([-w[1] for w in windows])          # longest runs first
+    with mp.get_context('fork').Pool(min(n_proc, len(jobs))) as pool:
+        res = pool.map(_member_worker, [jobs[i] for i in order], chunksize=1)
+    res = [res[list(order).index(i)] for i in range(len(jobs))]
+    arrays = {'members': np.array([m for _, _, m, _ in DRY_MEMBERS]), 'seed_offset': np.array([d for d, _, _, _ in DRY_MEMBERS]),
+              'wide': np.array([w for _, w, _, _ in DRY_MEMBERS]), 'worst_day': np.array([w for _, _, _, w in DRY_MEMBERS]),
+              'window': np.array(windows), 'pscale': np.array(DRY_PSCALE), 'n_draw': np.array(100000),
+              'odeint_rtol_atol': np.array(DRY_TOLS),
+              'columns': np.array(REACH_COLS), 'names': np.array(sorted(res[0][2])),
+              'values': np.array([[ov[k] for (_, _, ov) in res] for k in sorted(res[0][2])])}
+    for k, ((lo, hi), (m, R, _)) in enumerate(zip(windows, res)):
+        assert R.shape[0] == hi, (R.shape, hi)
+        arrays['R/%d' % k] = R[lo:hi]
+    np.savez_compressed(os.path.join(HERE, 'dry_members.npz'), **arrays)
+    print('dry_members.npz written')
+
+
+def dry_convergence_check(n_proc):
+    """Is the reference's own solution converged, in the RELATIVE sense, where the reach nearly dries up?  Three fixture members
+    (Vr down to 7e-5 mm) through the unmodified reference at (rtol, atol) = (1e-10, 1e-10) and (1e-12, 1e-15), against rows made with
+    (1e-12, 1e-12) (what dry_members.npz held when this check was first run; it now holds (1e-12, 1e-15) rows, so the second
+    comparison prints ~0): max relative difference per column over the fixture window."""
+    import multiprocessing as mp
+    from simplyp_amd import synthetic
+    z = np.load(os.path.join(HERE, 'dry_members.npz'), allow_pickle=False)
+    days = pd.date_range('1981-01-01', '2010-12-31')
+    picks = [9, 8, 5]
+    tols = [(1e-10, 1e-10), (1e-12, 1e-15)]
+    jobs = []
+    for k in picks:
+        dseed, wide, member, _ = DRY_MEMBERS[k]
+        hi = int(z['window'][k][1])
+        for t in tols:
+            jobs.append((synthetic.C3_SEED + dseed, 100000, member, '1981-01-01', days[hi - 1].strftime('%Y-%m-%d'), DRY_PSCALE, wide, t))
+    with mp.get_context('fork').Pool(min(n_proc, len(jobs))) as pool:
+        res = pool.map(_member_worker, jobs, chunksize=1)
+    i = 0
+    for k in picks:
+        lo, hi = (int(x) for x in z['window'][k])
+        for t in tols:
+            R = res[i][1][lo:hi]; i += 1
+            ref = z['R/%d' % k]
+            d = np.max(np.abs(R - ref) / np.abs(ref), axis=0)
+            print('member %d, odeint rtol %.0e atol %.0e vs the fixture (1e-12, 1e-12): %s'
+                  % (DRY_MEMBERS[k][2], t[0], t[1], ' '.join('%s %.1e' % (c, v) for c, v in zip(REACH_COLS, d))), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--long', action='store_true', help='also run the 1981-2010 scenario (minutes)')
@@ -414,6 +501,12 @@ def main():
         # the knee-aware controller lie between 1982 and 2005)
         from simplyp_amd import synthetic
         members_fixture('knee_members.npz', synthetic.C3_SEED, 100000, KNEE_MEMBERS, '1981-01-01', '2010-12-31', args.procs)
+        return
+    if args.only == 'dry':
+        dry_fixture(args.procs)
+        return
+    if args.only == 'dry-check':
+        dry_convergence_check(args.procs)
         return
     if args.only == 'heldout':
         # 16 members of a draw nothing was tuned on (seed C3_SEED + 7: what rank 7 of a weak-scaling bench runs), 3 years

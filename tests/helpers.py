@@ -151,3 +151,54 @@ def member_fixture_problem(fname, solver=None):
     tables = [z['R/%d' % m] for m in members]
     return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx, opts=opts,
                 members=members, met=met_df), tables
+
+
+def dry_fixture_problem(solver=None):
+    """Arrays + opts for the ten members of tests/golden/dry_members.npz -- the dry-reach regime: members of two 100 000-member draws
+    (one with the time constants widened x/÷ 2) with Qg_min ~ 0 on a climate with 0.6 x Tarland's precipitation and 1/0.6 x its PET,
+    each run through the unmodified reference at rtol=atol=1e-12 from 1981-01-01 to a year past its worst day
+    (tests/golden/make_golden.py --only dry) -- and what to compare: (problem dict over the days [0, max window end),
+    [(lo, hi, table[hi - lo, 9 reach columns]) per member]).  Parameter values are regenerated from the recorded seeds and checked."""
+    from simplyp_amd import synthetic, marshal, abi
+    z = np.load(os.path.join(GOLDEN, 'dry_members.npz'), allow_pickle=False)
+    members = [int(m) for m in z['members']]
+    windows = [(int(lo), int(hi)) for lo, hi in z['window']]
+    n_days = max(hi for _, hi in windows)
+    days = pd.date_range('1981-01-01', periods=n_days)
+    met_df, p_struc, p_SU, p_LU, p_SC, p, dyn = synthetic.tarland_inputs('1981-01-01', days[-1].strftime('%Y-%m-%d'), dynamic_epc0='y',
+                                                                         dynamic_erod='n')
+    names = [str(n) for n in z['names']]
+    over = {nm: np.empty(len(members)) for nm in names}
+    draws = {}
+    for k, (m, dseed, wide) in enumerate(zip(members, z['seed_offset'], z['wide'])):
+        key = (int(dseed), float(wide))
+        if key not in draws:
+            seed = synthetic.C3_SEED + int(dseed)
+            o = synthetic.monte_carlo_overrides(p, p_LU, int(z['n_draw']), seed=seed)
+            draws[key] = o if wide == 1.0 else synthetic.widen_overrides(o, p, p_LU, int(z['n_draw']), seed, float(wide))
+        for nm in names:
+            over[nm][k] = draws[key][nm][m]
+    for k, nm in enumerate(names):                                     # the generators still draw what the fixture recorded
+        np.testing.assert_array_equal(over[nm], z['values'][k])
+    marshal.prologue(p_SU, p_LU, p_SC, p)
+    up_ptr, up_idx, _ = marshal.topology(p_struc, p)
+    n = len(members)
+    mp = marshal.member_params(p, p_LU, n, over)
+    rp = marshal.reach_params(p_SC, p, n)
+    forcing, doy = marshal.forcing_arrays(met_df)
+    forcing = forcing.copy()
+    forcing[:, 0] *= float(z['pscale'])                                # the hydrological input x 0.6, PET / 0.6 (make_golden.run_reference)
+    forcing[:, 1] /= float(z['pscale'])
+    opts = abi.make_opts(solver, dynamic_epc0=True, run_mode_cal=True)
+    assert [str(c) for c in z['columns']] == ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay',
+                                              'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
+    tables = [(lo, hi, z['R/%d' % k]) for k, (lo, hi) in enumerate(windows)]
+    return dict(forcing=forcing, doy=doy, member_params=mp, reach_params=rp, up_ptr=up_ptr, up_idx=up_idx, opts=opts,
+                members=members, met=met_df), tables
+
+
+def dry_worst_per_member(got, tables, columns):
+    """max relative error of every fixture member over its window and the 9 reach columns; got [n_cols, D, 1, E] with `columns`."""
+    cols = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
+    return [max(max_rel_err(got[columns.index(c), lo:hi, 0, k], tab[:, j], floor=1e-300) for j, c in enumerate(cols))
+            for k, (lo, hi, tab) in enumerate(tables)]

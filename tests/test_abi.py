@@ -34,6 +34,12 @@ def test_enums_match_python_tables():
     out = re.search(r'enum \{\s*SIMPLYP_OUT_VSA = 0(.*?)SIMPLYP_N_OUT', txt, re.S).group(0)
     assert len(re.findall(r'SIMPLYP_OUT_[A-Z0-9_]+', out)) == marshal.N_OUT == 25
     assert marshal.MASK_REACH5 == (1 << 3) | (1 << 5) | (1 << 7) | (1 << 9) | (1 << 11)
+    # the 26th column (per-member snow depth) sits right after the reference's 25, in the header, the Python tables and the oracle
+    tail = re.search(r'SIMPLYP_N_OUT_REF,(.*?)SIMPLYP_N_OUT\b', txt, re.S).group(1)
+    assert re.findall(r'SIMPLYP_OUT_[A-Z0-9_]+', re.sub(r'/\*.*?\*/', '', tail, flags=re.S)) == ['SIMPLYP_OUT_D_SNOW']
+    assert re.search(r'SIMPLYP_OUT_D_SNOW\s*=\s*SIMPLYP_N_OUT_REF\s*,\s*SIMPLYP_N_OUT\b', re.sub(r'/\*.*?\*/', '', txt, flags=re.S))
+    assert marshal.ALL_COLUMNS.index('D_snow') == marshal.N_OUT == 25 and len(marshal.ALL_COLUMNS) == 26
+    assert marshal.MASK_D_SNOW == 1 << 25 and marshal.MASK_ALL == (1 << 25) - 1
     gv = re.search(r'SIMPLYP_GOF_Q = 0(.*?)SIMPLYP_N_GOF_VARS', txt, re.S).group(0)
     assert [n.lower() for n in re.findall(r'SIMPLYP_GOF_([A-Z]+)', gv)] == [v.lower() for v in abi.GOF_VARS]
     gs = re.search(r'SIMPLYP_GOFSTAT_N_OBS = 0(.*?)SIMPLYP_N_GOF_STATS', txt, re.S).group(0)
@@ -73,3 +79,17 @@ def test_out_bytes_and_host_argument_errors():
     if L.simplyp_device_count() == 0:
         assert L.simplyp_ctx_create(0, C.byref(h)) < 0
         assert b'not available' in L.simplyp_last_error(None)
+
+
+def test_no_kernel_uses_scratch():
+    """Every kernel of the library keeps its state in registers: hipcc's resource remarks (no GPU needed) show 0 bytes of scratch
+    per lane for all of them.  The snow instantiation of the chain kernel spilled 20 B per lane until round 4."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(engine.HERE), 'tools'))
+    import resource_usage
+    rows = resource_usage.resource_usage()
+    big = [r for r in rows if 'chain_kernel' in r['name'] or 'queue_kernel' in r['name']]
+    assert len(big) == 18 and len(rows) >= 28, [r['name'] for r in rows]
+    assert all(r['Occupancy [waves/SIMD]'] >= 1 for r in rows)
+    spilled = {r['name']: r['ScratchSize [bytes/lane]'] for r in rows if r['ScratchSize [bytes/lane]'] != 0}
+    assert not spilled, spilled

@@ -72,3 +72,52 @@ def test_nccl_sharded_run_and_gather(world):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+# ---- several GPUs from ONE process: run_simply_p_ensemble(devices=[...]) (SURVEY.md section 8b's batched entry) ----------------
+
+def _chain4_call(**kw):
+    import simplyp_amd as sp
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('chain4_val_2004')
+    E = 203                                                   # ragged blocks
+    rng = np.random.default_rng(5)
+    over = {'fc': 290 * rng.uniform(0.8, 1.2, E), 'T_g': 65 * rng.uniform(0.7, 1.3, E),
+            'L_reach': np.array([[3000.], [5000.], [7000.], [10000.]]) * rng.uniform(0.7, 1.3, (1, E)),
+            'f_TDP': rng.uniform(0.5, 0.9, E)}
+    return sp.run_simply_p_ensemble(met, p_struc, p_SU, p_LU, p_SC, p, dyn, overrides=over, **kw)
+
+
+@pytest.mark.parametrize('devices', [[0, 0], [0, 0, 0]])
+def test_devices_list_in_one_process_equals_one_device(devices):
+    """Two (three) engine contexts driven by host threads of one process -- on this box both on GPU 0; on an 8-GPU node
+    devices=[0..7] -- against the plain device=0 call: daily table, status, goodness of fit and waterbody bit-identical."""
+    if torch.cuda.device_count() <= max(devices):
+        pytest.skip("needs GPU %d" % max(devices))
+    met = helpers.scenario_inputs('chain4_val_2004')[0]
+    rng = np.random.default_rng(9)
+    obs = {4: __import__('pandas').DataFrame({'Q': rng.uniform(0.1, 2.0, len(met)), 'TDP': rng.uniform(0.01, 0.1, len(met))},
+                                             index=met.index)}
+    kw = dict(out_reaches=[2, 4], obs_dict=obs, waterbody=[2, 4])
+    one = _chain4_call(**kw)
+    many = _chain4_call(devices=devices, **kw)
+    assert many['stats']['bounds'][0][0] == 0 and many['stats']['bounds'][-1][1] == 203 and len(many['stats']['per_device']) == len(devices)
+    assert many['data'].shape == one['data'].shape and np.array_equal(many['data'], one['data'], equal_nan=True)
+    assert np.array_equal(many['status'], one['status'])
+    assert np.array_equal(many['gof']['data'], one['gof']['data'], equal_nan=True)
+    assert np.array_equal(many['waterbody']['data'], one['waterbody']['data'], equal_nan=True)
+    assert many['stats']['rhs_evals'] == one['stats']['rhs_evals']
+
+
+def test_devices_list_on_every_gpu_of_the_box():
+    """devices = every GPU this box has (1 here, 8 on the driver's node): same table as device=0."""
+    n = torch.cuda.device_count()
+    one = _chain4_call(out_reaches=[4])
+    many = _chain4_call(out_reaches=[4], devices=list(range(n)))
+    assert np.array_equal(many['data'], one['data'], equal_nan=True) and len(many['stats']['bounds']) == n
+
+
+def test_devices_list_device_resident_blocks():
+    res = _chain4_call(out_reaches=[4], devices=[0, 0], to_host=False)
+    assert isinstance(res['data'], list) and [t.shape[-1] for t in res['data']] == [102, 101]
+    one = _chain4_call(out_reaches=[4], to_host=False)
+    assert bool(torch.equal(torch.cat(res['data'], dim=-1), one['data']))

@@ -289,7 +289,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     for scaling, per_gpu, total in ((None, 1500, 3000), ('weak', 1500, 3000)):
         members = per_gpu if scaling == 'weak' else total
         cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--members', str(members)]
-        cmd += ['--scaling', scaling, '--no-cpu-baseline'] if scaling else []
+        cmd += ['--scaling', scaling, '--no-cpu-baseline'] if scaling else ['--secondary-scale', '0.002']
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -305,11 +305,24 @@ def test_bench_starts_its_own_ranks(tmp_path):
             assert j['cpu_baseline']['value'] > 0 and j['cpu_baseline']['cores'] >= 1
             assert j['parity']['golden']['knee_members']['worst_member_max_rel_err'] < 1e-6
             assert j['parity']['golden']['heldout_members']['worst_member_max_rel_err'] < 5e-7
+            assert j['parity']['golden']['dry_members']['worst_member_max_rel_err'] < j['parity']['golden']['dry_members']['bar']
+            assert j['cpu_baseline']['cores'] == j['cpu_baseline']['usable_cores'] and j['cpu_baseline']['reference_python']['value'][0] > 100
+            # the secondary legs at rehearsal size (--secondary-scale): the leg that can scale strongly is ONE ensemble split over both ranks
+            s1 = j['secondary']['strong_1m']
+            assert s1['scaling'] == 'strong' and s1['members_total'] == 2000 and s1['members_per_gpu'] == 1000 and len(s1['per_rank']['kernel_ms']) == 2
+            assert s1['parity']['within_bar'] is True and s1['value'] > 0
+            c4 = j['secondary']['c4']
+            assert c4['reaches'] == 256 and c4['days'] == 18262 and c4['members_per_gpu'] == 20 and c4['steps'] == 1 and c4['warmup'] == 0
+            assert c4['parity']['within_bar'] is True and c4['parity']['rows'].startswith('the first 730') and c4['members_flagged'] == 0
+            assert j['secondary']['c5']['parity']['within_bar'] is True
+            assert j['value_weak']['members_per_gpu'] == 200
 
 
 def test_default_bench_line_carries_the_secondary_legs(tmp_path):
-    """The driver's `python bench.py` (N = 1, no flags): the headline C3 line plus, after the timed region, BASELINE C2 and C5
-    and the goodness-of-fit-only pass, cpu_baseline, value_weak (= value at N = 1).  Run here with 1 step."""
+    """The driver's `python bench.py` (N = 1, no flags): the headline C3 line plus, after the timed region, BASELINE C2, C5, C4 AT ITS
+    STATED SIZE (one pass of 10 000 x 256 x 18 262) and the 1M-member strong-scaling leg, each with a sample of its benchmarked table
+    against the CPU oracle, the goodness-of-fit-only pass, cpu_baseline on every usable core, value_weak (= value at N = 1).
+    Run here with 1 step."""
     import json
     env = dict(os.environ)
     env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
@@ -324,6 +337,15 @@ def test_default_bench_line_carries_the_secondary_legs(tmp_path):
     sec = j['secondary']
     assert sec['c2']['replicas_bit_identical'] is True and sec['c2']['host_rows_equal'] is True and sec['c2']['lanes_per_member'] >= 4
     assert sec['c5']['parity_grade'] is False and sec['c5']['value'] > j['value']
+    assert sec['c5']['parity']['within_bar'] is True and sec['c5']['members_per_gpu'] == 125000
+    c4 = sec['c4']
+    assert (c4['members_per_gpu'], c4['reaches'], c4['days'], c4['steps']) == (10000, 256, 18262, 1) and c4['members_flagged'] == 0
+    assert c4['parity']['within_bar'] is True and c4['roofline']['frac'] > 0 and c4['rhs_evals_per_catchment_day'] > 50
+    assert c4['table'] == 'pinned host memory' and c4['streamed_chunks'] > 0
+    s1 = sec['strong_1m']
+    assert s1['members_total'] == 1000000 and s1['scaling'] == 'strong' and s1['parity']['within_bar'] is True and s1['members_flagged'] == 0
+    assert j['cpu_baseline']['cores'] == j['cpu_baseline']['usable_cores'] >= 1
+    assert j['parity']['golden']['dry_members']['worst_member_max_rel_err'] < j['parity']['golden']['dry_members']['bar']
     assert sec['c3_gof_only']['value'] > j['value'] and sec['c3_gof_only']['gof_ms'] > 0 and sec['c3_gof_only']['best_member_nse_q'] > 0.0
     assert j['value_weak']['same_run_as_value'] is True and j['value_weak']['value'] == j['value']
 

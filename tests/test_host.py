@@ -313,6 +313,6 @@ def test_bench_parent_launches_its_own_ranks_without_touching_the_gpu(monkeypatc
     assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '4', '--steps', '2', '--scaling', 'strong']
     assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
-    assert set(bench.CONFIGS) == {'c2', 'c3', 'c4', 'c5'} and bench.CONFIGS['c2']['bytes_per_cd'] == 216.0
+    assert set(bench.CONFIGS) == {'c2', 'c3', 'c4', 'c5', 'strong_1m'} and bench.CONFIGS['strong_1m']['scaling'] == 'strong' and bench.CONFIGS['c2']['bytes_per_cd'] == 216.0
     assert bench.CONFIGS['c3']['bytes_per_cd'] == 56.0 and not bench.CONFIGS['c5']['parity_grade']
     assert bench.kernel_source_hash() == bench.kernel_source_hash() and len(bench.kernel_source_hash()) == 16

@@ -269,3 +269,19 @@ def test_oracle_expansive_reach_on_a_drier_climate(oracle_lib):
     worst = (np.abs(out - truth) / np.maximum(np.abs(truth), 1e-300)).max(axis=(0, 1, 2))
     assert worst.max() < 1e-6, dict(zip(sel.tolist(), worst))
     assert truth[1].min() < 1e-3
+
+
+def test_oracle_default_solver_in_the_dry_reach_regime_against_the_reference(oracle_lib):
+    """The regime the controller's expansive-reach rule (include/simplyp_controller.h: SIMPLYP_CTRL_EXPAND) was written for, pinned to the
+    REFERENCE (round 3 had it kernel-vs-kernel only): ten members whose reach nearly dries up (Qg_min ~ 0, min Qr 1e-5 ... 1e-3 mm/d)
+    and is wetted again, on a climate with 0.6 x Tarland's precipitation -- six of draw C3_SEED + 12, four of a draw with the time
+    constants widened x/÷ 2 (the 7.2e-7 case of profiles/r03_tolerance) -- against tables the unmodified reference made with odeint at
+    rtol=atol=1e-12 (tests/golden/dry_members.npz), two years around each member's worst day: north_star's bar on all 9 reach outputs."""
+    m, tables = helpers.dry_fixture_problem()
+    out, status, _ = oracle_lib.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'],
+                                    n_threads=8)
+    assert status.max() == 0
+    worst = helpers.dry_worst_per_member(out, tables, marshal.OUT_COLUMNS)
+    assert max(worst) < 1e-6, dict(zip(m['members'], worst))
+    qr = out[marshal.OUT_COLUMNS.index('Qr')]
+    assert min(float(qr[lo:hi, 0, k].min()) for k, (lo, hi, _) in enumerate(tables)) < 1e-3      # the reaches do nearly dry up

@@ -167,3 +167,21 @@ def test_snow_depth_column_needs_the_snow_module(engine0):
     assert np.array_equal(res['data'][1, :, 0, 0], met['D_snow_end'].to_numpy())       # member 0 = the workbook = the reference's column
     with pytest.raises(ValueError, match='snow_in_kernel'):
         sp.run_simply_p_ensemble(met.copy(), p_struc, p_SU, p_LU, p_SC, p, dyn, n_members=2, outputs=['Qr', 'D_snow'])
+
+
+def test_snow_depth_column_together_with_goodness_of_fit_and_waterbody(engine0):
+    """the 26th column's bit is outside SIMPLYP_MASK_ALL; simplyp_gof / _spearman / _waterbody used to refuse a table
+    that carries it (after the whole ensemble had run).  It is the highest bit, so the offsets of Qr and the fluxes do not move:
+    statistics and sums equal those of a run without the column."""
+    import pandas as pd
+    met, p_struc, p_SU, p_LU, p_SC, p, dyn = helpers.scenario_inputs('confluence3_nc_2004')
+    f = np.array([2.0, 2.74, 3.5, 1.2])
+    rng = np.random.default_rng(2)
+    obs = {3: pd.DataFrame({'Q': rng.uniform(0.1, 2.0, len(met)), 'PP': rng.uniform(0.01, 0.1, len(met))}, index=met.index)}
+    kw = dict(overrides={'f_DDSM': f}, obs_dict=obs, waterbody=[1, 2], spearman=True)
+    with_snow = sp.run_simply_p_ensemble(met.copy(), p_struc, p_SU, p_LU.copy(), p_SC.copy(), p, dyn, outputs=['Qr', 'D_snow'], **kw)
+    without = sp.run_simply_p_ensemble(met.copy(), p_struc, p_SU, p_LU.copy(), p_SC.copy(), p, dyn, outputs=['Qr'], **kw)
+    assert with_snow['columns'][-1] == 'D_snow' and 'D_snow' not in without['columns']
+    assert np.array_equal(with_snow['gof']['data'], without['gof']['data'], equal_nan=True)
+    assert np.array_equal(with_snow['gof']['spearman'], without['gof']['spearman'], equal_nan=True)
+    assert np.array_equal(with_snow['waterbody']['data'], without['waterbody']['data'], equal_nan=True)
