@@ -805,6 +805,24 @@ def reference_python_rate():
         return {"value": None, "note": "tests/golden/series_meta.json not readable: %s" % ex}
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of run time the container may use per period (cgroup v2 cpu.max, v1 cpu.cfs_quota_us), or None = unlimited."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            q, per = fh.read().split()[:2]
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as fh:
+            q = float(fh.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh:
+            per = float(fh.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(prob, D, S, budget_s=20.0):
     """The CPU oracle (a C port of the reference's equations with the same solver; the Python reference cannot travel
     to this box) timed on the host cores, on a bounded sample of the same workload: ALL the cores this process may use (the
@@ -827,23 +845,37 @@ def cpu_baseline(prob, D, S, budget_s=20.0):
         return time.perf_counter() - t0
 
     try:
-        usable = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        usable = os.cpu_count() or 1
+        affinity = os.cpu_count() or 1
+    quota = cgroup_cpu_quota()
+    # every core this process may USE: the affinity mask, cut to the container's CPU quota when there is one (128 runnable
+    # threads on a 16-CPU quota are throttled, not faster)
+    usable = max(1, min(affinity, int(quota + 0.5))) if quota else affinity
     E = prob['member_params'].shape[1]
-    # calibrate the per-member cost on this host with a small one-thread run, then size both samples by time
-    n_cal = max(1, min(E, 8))
+
+    def say(msg):
+        print("[bench cpu_baseline] %s" % msg, file=sys.stderr, flush=True)
+    # calibrate the per-member cost on this host with a small one-thread run, then a short all-thread run, and size the samples by time
+    n_cal = max(1, min(E, 4))
     dt_cal = leg(n_cal, 1)
     per_member = dt_cal / n_cal                              # core-seconds per member
+    say("1 thread: %.3f s per member" % per_member)
     n_one = max(n_cal, min(E, int(6.0 / per_member)))
     dt_one = leg(n_one, 1) if n_one > n_cal else dt_cal
-    n_all = max(usable, min(E, int(budget_s * usable / per_member)))
-    n_all = min(E, n_all)
-    dt_all = leg(n_all, usable)
+    n_pilot = min(E, 2 * usable)
+    dt_pilot = leg(n_pilot, usable)
+    say("%d threads: %d members in %.2f s" % (usable, n_pilot, dt_pilot))
+    n_all = min(E, max(n_pilot, int(budget_s * n_pilot / max(dt_pilot, 1e-3))))
+    n_all = min(n_all, int(8 * budget_s * usable / per_member) + n_pilot)          # (a pilot that ran suspiciously fast does not size a runaway sample)
+    dt_all = leg(n_all, usable) if n_all > n_pilot else dt_pilot
+    say("%d threads: %d members in %.2f s" % (usable, n_all, dt_all))
     return {"value": n_all * S * D / dt_all, "unit": "catchment-days/s", "cores": usable, "kind": "port",
-            "usable_cores": usable, "host_cpu_count": os.cpu_count(),
+            "usable_cores": usable, "affinity_cores": affinity, "cgroup_cpu_quota": quota, "host_cpu_count": os.cpu_count(),
+            "effective_parallelism": per_member * n_all / dt_all,      # one-thread seconds per member x members / wall: the cores the run really got
             "sample": "first %d members of the same ensemble, all %d reaches and %d days, %d OpenMP threads (every core this "
-                      "process may use), %.1f s wall" % (n_all, S, D, usable, dt_all),
+                      "process may use: affinity mask %d, container CPU quota %s), %.1f s wall"
+                      % (n_all, S, D, usable, affinity, ("%.1f" % quota) if quota else "none", dt_all),
             "one_core": {"value": n_one * S * D / dt_one, "cores": 1,
                          "sample": "first %d members, 1 thread, %.1f s wall" % (n_one, dt_one)},
             "reference_python": reference_python_rate()}
