@@ -462,7 +462,7 @@ def main():
             "config": {"workload": "%s; %d members %s; output: %s" % (cfg['what'] % dict(rtol=opts.rtol), n_arg, "per GPU" if scaling == 'weak' else "in all, split over the GPUs", cfg['out']),
                        "name": args.config, "members_per_gpu": e_local, "members_total": e_total, "reaches": S, "days": D,
                        "outputs": marshal.columns_of_mask(opts.out_mask),
-                       "solver": {k: getattr(opts, k) for k in ('integrator', 'rtol', 'atol', 'project_vr')},
+                       "solver": dict({k: getattr(opts, k) for k in ('integrator', 'rtol', 'atol', 'project_vr')}, second_pair_used=int(stats.get('stiff_pair', 0))),
                        "parity_grade": cfg['parity_grade'],
                        "parallelism": "ensemble shards (ensemble.run_sharded), %d GPU(s), no data-path collective; final gather "
                                       "of per-member summaries over %s" % (world, 'RCCL' if backend == 'nccl' else backend)},
@@ -559,7 +559,8 @@ def leg_secondary(b, config, steps=3, warmup=1):
     stats = res['stats']
     d = None
     if b.rank == 0:
-        d = {"workload": cfg['what'] % dict(rtol=leg.opts.rtol) + "; %d members per GPU; output: %s" % (leg.e_local, cfg['out']),
+        d = {"workload": cfg['what'] % dict(rtol=leg.opts.rtol) + "; %s; output: %s" % (
+                 "%d members per GPU" % leg.e_local if leg.scaling == 'weak' else "%d members in all, split over the GPUs" % leg.e_total, cfg['out']),
              "value": leg.cd_per_step / (elapsed / steps), "unit": "catchment-days/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
              "warmup": warmup, "scaling": leg.scaling, "members_total": leg.e_total, "members_per_gpu": leg.e_local,
              "reaches": leg.S, "days": leg.D, "per_rank": {"kernel_ms": [round(x, 3) for x in k_ranks]},
@@ -568,6 +569,7 @@ def leg_secondary(b, config, steps=3, warmup=1):
              "roofline": {"bound": "hbm", "frac": leg.roofline_frac(k_ms), "bytes_per_catchment_day": cfg['bytes_per_cd']},
              "rhs_evals_per_catchment_day": st[-1]['rhs_evals'] / leg.cd_rank, "simt_efficiency": stats.get('simt_efficiency'),
              "rejected_per_step": (st[-1]['rejected'] / float(st[-1]['steps'])) if st[-1]['steps'] else None,
+             "second_pair_used": int(stats.get('stiff_pair', 0)),      # opts.stiff_pair resolved to on (auto: reach networks)
              "streamed_chunks": int(st[-1]['streamed_chunks']),
              "lanes_per_member": int(stats.get('lanes_per_member', 1) or 1), "members_flagged": int((res['status'] != 0).sum().item())}
         if config != 'c2' and not b.args.no_parity:      # (c2: every member is the base member, which parity.golden pins to the reference)

@@ -168,6 +168,12 @@ typedef struct {
                                 SIMDs through the task queue where one-lane waves would occupy a third of them --, else 1.
                                 lanes_per_wave then counts member slots of 4 lanes (at most 16).  Results are unchanged bit
                                 for bit for every member whose status is 0.                                      */
+    int32_t  stiff_pair;     /* integrator 2: attempts whose step is bound by Cash-Karp's stability interval (a reach far down a
+                                network relaxes at several hundred per day; |h x rate| <= 3.73) are taken by a second, stability-
+                                optimised explicit 4(3) pair of the same 6 stages (include/simplyp_controller.h SIMPLYP_STIFF_*),
+                                chosen lane by lane and attempt by attempt from the lane's own state.  0 = auto: on for reach
+                                networks (S > 1), off for a single reach; > 0 on; < 0 off.  Same <= 1e-6 parity bar; a third
+                                fewer attempts on BASELINE config C4.                                             */
 } simplyp_opts;
 
 typedef struct {
@@ -195,6 +201,8 @@ typedef struct {
     uint64_t queue_longest_wait_polls;  /* the longest of them, in polls (~2 us each)                                   */
     uint64_t queue_longest_stall_polls; /* the longest stretch of polls, inside any such wait, during which NO task of the run
                                 completed: what the wait's bound counts (simplyp_sync)                                 */
+    int32_t  stiff_pair;     /* 1 when the run used the stability-optimised second pair (opts.stiff_pair resolved to on)  */
+    int32_t  reserved0;
 } simplyp_stats;
 
 typedef struct simplyp_ctx simplyp_ctx;

@@ -55,4 +55,45 @@
 #define SIMPLYP_CTRL_FAC_MIN 0.2
 #define SIMPLYP_CTRL_FAC_MAX 5.0
 
+
+/* ---- the stability-optimised second pair of integrator 2 (opts.stiff_pair) -----------------------------------
+ * Far down a reach network the flow relaxes at rate = cQ Qr**b_Q of up to several hundred per day; once the transient that follows
+ * midnight has died away, Cash-Karp's steps there are bound by its real stability interval (|h x rate| <= 3.73), not by accuracy:
+ * half of config C4's attempts (tools/probe_c4_steps.py).  For an attempt whose step is longer than Z_ON relaxation times -- and has no
+ * knee of a gate within reach -- a lane switches to this pair: 6 stages, order 4 with an embedded order 3, |R| <= 0.97 and
+ * |R_hat| <= 1 on [-9.01, 0], every internal stage polynomial <= 1.5 there, Cash-Karp's sparsity (b2 = b5 = 0, e2 = 0), so the attempt
+ * loop runs the same instructions with other constants.  Steps are capped at CAP relaxation times.  Derivation (least squares from
+ * random starts, then a projection onto the 12 order conditions): tools/derive_stiff_pair.py --beta 9 --pmax 1.5 --seed 34 --trial 53.
+ * E_i = b_i - bhat_i.  The step-size factor of such an attempt is SAFETY * err^ERR_EXP (a third-order estimate). */
+#define SIMPLYP_STIFF_Z_ON 3.4
+#define SIMPLYP_STIFF_CAP 8.1
+#define SIMPLYP_STIFF_ERR_EXP (-0.25)
+#define SIMPLYP_STIFF_A21 0.12853527643260251
+#define SIMPLYP_STIFF_A31 0.16351994308561854
+#define SIMPLYP_STIFF_A32 0.19797306142138452
+#define SIMPLYP_STIFF_A41 0.049733203403888065
+#define SIMPLYP_STIFF_A42 -0.031561611797594993
+#define SIMPLYP_STIFF_A43 0.41110922959004331
+#define SIMPLYP_STIFF_A51 -0.24502075792174899
+#define SIMPLYP_STIFF_A52 0.34132654630326525
+#define SIMPLYP_STIFF_A53 0.29025955186572305
+#define SIMPLYP_STIFF_A54 0.43141124249147206
+#define SIMPLYP_STIFF_A61 -0.035331946161144254
+#define SIMPLYP_STIFF_A62 0.29197800440542732
+#define SIMPLYP_STIFF_A63 0.058008315542356415
+#define SIMPLYP_STIFF_A64 0.35949958123859993
+#define SIMPLYP_STIFF_A65 0.1960184892363403
+#define SIMPLYP_STIFF_B1 0.12617507659604874
+#define SIMPLYP_STIFF_B3 0.29065812274966046
+#define SIMPLYP_STIFF_B4 0.25522498620491596
+#define SIMPLYP_STIFF_B6 0.32794181444937487
+#define SIMPLYP_STIFF_E1 -0.0080682924634790099
+#define SIMPLYP_STIFF_E3 0.011178207329606782
+#define SIMPLYP_STIFF_E4 0.018364840372072311
+#define SIMPLYP_STIFF_E5 -0.12955476832078688
+#define SIMPLYP_STIFF_E6 0.10808001308258683
+/* opts.stiff_pair: 0 = auto (on for a reach network, S > 1: a single reach is never far from its headwater), > 0 on, < 0 off;
+ * integrator 2 only */
+#define SIMPLYP_STIFF_PAIR_ON(opt, S) ((opt) > 0 || ((opt) == 0 && (S) > 1))
+
 #endif /* SIMPLYP_CONTROLLER_H */

@@ -372,11 +372,38 @@ static void ode_aug(const double* z, const ode_params* p, double invKv, double* 
 
 /* Same step-size rule as cashkarp_day (the kernel mirrors both).  y is the reference's 12-vector; slot 3
  * (Vr) is returned on its invariant. */
-static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, double T, double rtol, double atol,
+/* Probe hooks of tools/probe_c4_steps.py (round 4: where do a reach network's attempts go?), off by default.
+ *   reach trace: [S][12] doubles per reach -- [0] attempts, [1] rejected, [2..7] accepted steps binned by h x (cQ Qr**b_Q), the step in
+ *   units of the reach's relaxation time: < 0.5, < 1, < 2, < 3, < 4, >= 4 (Cash-Karp's real stability interval ends at 3.73);
+ *   [8] sum of that rate over the attempts, [9] rejections with h x rate >= 2.  (Counters are shared by the OpenMP threads: a benign
+ *   race, the probe's figures are statistics.)
+ *   stability cap: attempts are cut to h x rate <= cap (0 = off): what a controller that never probes the stability limit would do. */
+static double* g_reach_trace = NULL;
+static _Thread_local int g_trace_reach = 0;
+static double g_stab_cap = 0.0;
+void simplyp_oracle_set_reach_trace(double* buf) { g_reach_trace = buf; }
+void simplyp_oracle_set_stab_cap(double c) { g_stab_cap = c; }
+
+/* The stability-optimised pair of integrator 2 (opts.stiff_pair; include/simplyp_controller.h SIMPLYP_STIFF_*, derived by
+ * tools/derive_stiff_pair.py): 6 stages, order 4 with an embedded order 3, stable on the real axis down to -9.01 with every
+ * stage polynomial <= 1.5 there, the sparsity of Cash-Karp's weights.  erk_aug_day uses it, attempt by attempt, where the
+ * step is bound by the stability of Cash-Karp (|h x rate| <= 3.73, rate = cQ Qr**b_Q: a reach far down a network), not by
+ * accuracy -- the rule is in erk_aug_day and mirrored by ck_day<SysAug, true> / ck_day_quad<true> in the kernels. */
+static const erk_tableau TAB_STIFF = {
+    6, 0,
+    {{0}, {SIMPLYP_STIFF_A21}, {SIMPLYP_STIFF_A31, SIMPLYP_STIFF_A32}, {SIMPLYP_STIFF_A41, SIMPLYP_STIFF_A42, SIMPLYP_STIFF_A43},
+     {SIMPLYP_STIFF_A51, SIMPLYP_STIFF_A52, SIMPLYP_STIFF_A53, SIMPLYP_STIFF_A54},
+     {SIMPLYP_STIFF_A61, SIMPLYP_STIFF_A62, SIMPLYP_STIFF_A63, SIMPLYP_STIFF_A64, SIMPLYP_STIFF_A65}},
+    {SIMPLYP_STIFF_B1, 0, SIMPLYP_STIFF_B3, SIMPLYP_STIFF_B4, 0, SIMPLYP_STIFF_B6},
+    {SIMPLYP_STIFF_E1, 0, SIMPLYP_STIFF_E3, SIMPLYP_STIFF_E4, SIMPLYP_STIFF_E5, SIMPLYP_STIFF_E6},
+    {0}, 0, SIMPLYP_STIFF_ERR_EXP};
+
+static void erk_aug_day(const erk_tableau* tab, const erk_tableau* stiff, double* y, const ode_params* p, double T, double rtol, double atol,
                         int max_steps, double* h_carry, integ_stats* st)
 {
     double k[ERK_MAX_STAGES][NZ], zt[NZ], zn[NZ], z[NZ];
     const int ns = tab->ns;
+    const erk_tableau* const tab_default = tab;
     int have_k0 = 0;                 /* FSAL pairs: k[0] already holds the derivative at the current point */
     /* (the step size carried over the day boundary belongs to the smooth end of a day; the forcing jumps at midnight and the first
      * attempt of the new day with it was rejected on 85 % of the member-days: SysAug::DAY_START of it is the better guess) */
@@ -394,6 +421,11 @@ static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, 
         if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
         int last_chance = (attempts + 1 >= max_steps);
         if (last_chance) hh = rem;
+        /* opts.stiff_pair: an attempt never reaches further than SIMPLYP_STIFF_CAP relaxation times of the reach (the second pair's real
+         * stability interval ends at 9.01); the rate is the carried state cQ Qr**b_Q itself */
+        const double stiff_rate = (p->a_Q * (8.64 * 10000) / ((1 - p->b_Q) * (p->L_reach))) * z[9];
+        if (stiff && !last_chance && hh * stiff_rate > SIMPLYP_STIFF_CAP) hh = SIMPLYP_STIFF_CAP / stiff_rate;
+        if (g_stab_cap > 0.0 && !last_chance && hh * stiff_rate > g_stab_cap) hh = g_stab_cap / stiff_rate;      /* (probe hook) */
         if (!have_k0) { ode_aug(z, p, invKv, k[0]); st->rhs += 1; }
         /* Aim at the knee (SysAug::KNEE_*): time to the nearest knee of a gate along the first slope; a knee inside the step
          * ends the step just past it, so that the right-hand side is smooth over all but its last few percent. */
@@ -421,6 +453,16 @@ static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, 
             const double look = AUG_KINK_REACH * hh;
             kink = hs < look;
             kink_gw = (hg < look) | (kink & (ugd > 0.0));
+        }
+        /* Which pair takes this attempt.  Cash-Karp (5th order) unless the step is longer than SIMPLYP_STIFF_Z_ON relaxation times of the
+         * reach, where Cash-Karp's own stability ends (3.73): then the stability-optimised 4(3) pair -- except for an attempt that has a
+         * knee of a gate within reach or was aimed at one: its estimate is what the knee rules were tuned on (with the second pair there a
+         * storm day of a 256-reach chain came out at 4.7e-7 instead of 1.2e-7), so such an attempt is shortened to Cash-Karp's interval
+         * instead.  A lane's choice depends on its own state only: results do not depend on which members share a wavefront. */
+        tab = tab_default;
+        if (stiff && hh * stiff_rate > SIMPLYP_STIFF_Z_ON) {
+            if (!(kink || kink_gw || targeted)) tab = stiff;
+            else if (!last_chance) hh = SIMPLYP_STIFF_Z_ON / stiff_rate;
         }
         for (int s = 1; s < ns; ++s) {
             for (int i = 0; i < NZ; ++i) {
@@ -467,6 +509,14 @@ static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, 
         if (!(err < 1.0e300)) bad = 1;
         for (int i = 0; i < 11; ++i) if (!(fabs(zn[i]) < 1.0e300)) bad = 1;
         ++attempts;
+        if (g_reach_trace) {      /* (probe hook) */
+            double* tr = g_reach_trace + 12 * (size_t)g_trace_reach;
+            const double hl = hh * stiff_rate;
+            const int acc = !bad && (err <= 1.0 || last_chance);
+            tr[0] += 1; tr[8] += stiff_rate;
+            if (!acc) { tr[1] += 1; if (hl >= 2.0) tr[9] += 1; }
+            else tr[2 + (hl < 0.5 ? 0 : hl < 1 ? 1 : hl < 2 ? 2 : hl < 3 ? 3 : hl < 4 ? 4 : 5)] += 1;
+        }
         if (last_chance) st->capped = 1;
         if (bad && (last_chance || hh <= 1.0e-9 * T)) {
             for (int i = 0; i < NY; ++i) y[i] = NAN;
@@ -502,9 +552,9 @@ static void erk_aug_day(const erk_tableau* tab, double* y, const ode_params* p, 
 }
 
 static void cashkarp_aug_day(double* y, const ode_params* p, double T, double rtol, double atol,
-                             int max_steps, double* h_carry, integ_stats* st)
+                             int max_steps, double* h_carry, integ_stats* st, int stiff)
 {
-    erk_aug_day(&TAB_CASHKARP, y, p, T, rtol, atol, max_steps, h_carry, st);
+    erk_aug_day(&TAB_CASHKARP, stiff ? &TAB_STIFF : NULL, y, p, T, rtol, atol, max_steps, h_carry, st);
 }
 
 /* ------------------------------------------------------------------------------------- */
@@ -715,6 +765,8 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
                        int n_out_reaches, int n_integ, double* out, int32_t* status, integ_stats* st)
 {
     const int E = dims->E, S = dims->S, D = dims->D;
+    /* opts.stiff_pair: 0 = auto (reach networks), > 0 on, < 0 off -- SIMPLYP_STIFF_PAIR_ON in include/simplyp_controller.h, the rule the library uses */
+    const int stiff_pair = SIMPLYP_STIFF_PAIR_ON(o->stiff_pair, S) && n_integ == SIMPLYP_INTEG_CASHKARP_AUG;
     const double* Pser = forcing + (size_t)(fom ? fom[e] : 0) * (o->snow ? 3 : 2) * D;   /* Precipitation when o->snow */
     const double* Eser = Pser + D;
     const double* Tser = Eser + D;                                                        /* T_air (o->snow only) */
@@ -852,15 +904,16 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
 
             /* model.py:640 -- the one place that is not a restatement (see header) */
             const uint64_t attempts_before = st->steps + st->rejected;
+            g_trace_reach = s;
             if (n_integ == SIMPLYP_INTEG_RK4) rk4_day(y, &op, o->step_len, o->substeps, st);
             else if (n_integ == SIMPLYP_INTEG_CASHKARP_AUG)
-                cashkarp_aug_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
+                cashkarp_aug_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st, stiff_pair);
             else if (n_integ == SIMPLYP_INTEG_CASHKARP_AUG_F32)
                 cashkarp_aug_f32_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else if (n_integ == ORACLE_INTEG_TSIT5_AUG)
-                erk_aug_day(&TAB_TSIT5, y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
+                erk_aug_day(&TAB_TSIT5, NULL, y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else if (n_integ == ORACLE_INTEG_DOP853_AUG)
-                erk_aug_day(tab_dop853(), y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
+                erk_aug_day(tab_dop853(), NULL, y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else cashkarp_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG && n_integ != SIMPLYP_INTEG_CASHKARP_AUG_F32 && n_integ != ORACLE_INTEG_TSIT5_AUG && n_integ != ORACLE_INTEG_DOP853_AUG) {
                 /* Drift control (not in the reference).  The reference's own equations (:127-131) imply

@@ -27,7 +27,7 @@ class Opts(C.Structure):
                 ('step_len', C.c_double), ('project_vr', C.c_int32), ('balance', C.c_int32),
                 ('balance_pilot_days', C.c_int32), ('out_slot_order', C.c_int32),
                 ('time_chunk_days', C.c_int32), ('n_periods', C.c_int32), ('snow', C.c_int32), ('lanes_per_wave', C.c_int32),
-                ('lanes_per_member', C.c_int32)]
+                ('lanes_per_member', C.c_int32), ('stiff_pair', C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -35,7 +35,8 @@ class Stats(C.Structure):
                 ('kernel_ms', C.c_double), ('pilot_ms', C.c_double), ('simt_efficiency', C.c_double), ('n_launches', C.c_int32), ('balanced', C.c_int32),
                 ('queued', C.c_int32), ('lanes_per_wave', C.c_int32), ('lanes_per_member', C.c_int32), ('streamed_chunks', C.c_int32),
                 ('d2h_tail_ms', C.c_double), ('wall_ms', C.c_double), ('stream_gbs', C.c_double),
-                ('queue_waits', C.c_uint64), ('queue_longest_wait_polls', C.c_uint64), ('queue_longest_stall_polls', C.c_uint64)]
+                ('queue_waits', C.c_uint64), ('queue_longest_wait_polls', C.c_uint64), ('queue_longest_stall_polls', C.c_uint64),
+                ('stiff_pair', C.c_int32), ('reserved0', C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}
@@ -73,7 +74,8 @@ GOF_STATS = ['N obs', 'NSE', 'log NSE', 'r2', 'Bias (%)', 'nRMSD (%)', 'sum_log_
 # ensemble with a margin (1e-8 before the step controller learned about the knees
 # of the gates, round 2).
 DEFAULT_SOLVER = dict(integrator='cashkarp_aug', substeps=8, rtol=1e-7, atol=1e-12, max_steps=4000, project_vr=1,
-                      balance=2, balance_pilot_days=0, out_slot_order=0, time_chunk_days=0, lanes_per_wave=0, lanes_per_member=0)
+                      balance=2, balance_pilot_days=0, out_slot_order=0, time_chunk_days=0, lanes_per_wave=0, lanes_per_member=0,
+                      stiff_pair=0)
 
 
 def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=True, sc_qr0=0,
@@ -96,6 +98,7 @@ def make_opts(solver=None, dynamic_epc0=False, dynamic_erod=False, run_mode_cal=
     o.time_chunk_days = int(s['time_chunk_days'])
     o.lanes_per_wave = int(s['lanes_per_wave'])
     o.lanes_per_member = int(s['lanes_per_member'])
+    o.stiff_pair = int(s['stiff_pair'])
     o.dynamic_epc0 = int(bool(dynamic_epc0))
     o.dynamic_erod = int(bool(dynamic_erod))
     o.run_mode_cal = int(bool(run_mode_cal))

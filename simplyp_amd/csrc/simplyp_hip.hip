@@ -72,6 +72,7 @@ struct simplyp_ctx {
     std::chrono::steady_clock::time_point t_begin;
     int lanes = 64;           // member slots per wavefront of the last run
     int team = 1;             // lanes per member of the last run (1, or 4 = one member per DPP quad)
+    int stiff = 0;            // last run used the stability-optimised second pair (opts.stiff_pair)
     int queued = 0;           // last run used the task-queue kernel
     int n_simd_slots = 1024;  // CUs x 4 SIMDs: wave slots at one resident wave per SIMD
     int balanced = 0;         // last run used the cost-sorted member order
@@ -715,6 +716,9 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     ctx->lanes = lanes;
     const unsigned gx = (unsigned)((E + lanes - 1) / lanes);
     const bool snow = opts->snow != 0;
+    // opts.stiff_pair (integrator 2): attempts bound by Cash-Karp's stability interval go to the second pair; auto = reach networks
+    const bool stiff = opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG && SIMPLYP_STIFF_PAIR_ON(opts->stiff_pair, S);
+    ctx->stiff = stiff ? 1 : 0;
     // one launch of the chain kernel: k.chain_ptr / k.chain_reach describe n_chains mutually independent chains
     auto launch_chains = [&](const simplyp::KernelArgs& k, unsigned n_chains, unsigned n_windows = 1u) -> int {
         dim3 grid(gx, n_chains, n_windows), block(simplyp::WAVE, 1, 1);
@@ -726,6 +730,15 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
         if (opts->integrator == SIMPLYP_INTEG_RK4) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_RK4, 1);
         else if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP, 1);
         else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG_F32, 1);
+        else if (stiff) {
+#define SIMPLYP_LAUNCH_CHAIN_STIFF(TEAM)                                                                                                        \
+    do {                                                                                                                                        \
+        if (snow) hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP_AUG, true, TEAM, true>), grid, block, 0, ctx->stream, k);   \
+        else hipLaunchKernelGGL((simplyp::simplyp_chain_kernel<SIMPLYP_INTEG_CASHKARP_AUG, false, TEAM, true>), grid, block, 0, ctx->stream, k);       \
+    } while (0)
+            if (team == 4) SIMPLYP_LAUNCH_CHAIN_STIFF(4); else SIMPLYP_LAUNCH_CHAIN_STIFF(1);
+#undef SIMPLYP_LAUNCH_CHAIN_STIFF
+        }
         else if (team == 4) SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG, 4);
         else SIMPLYP_LAUNCH_CHAIN(SIMPLYP_INTEG_CASHKARP_AUG, 1);
 #undef SIMPLYP_LAUNCH_CHAIN
@@ -945,6 +958,15 @@ static int run_async_body(simplyp_ctx* ctx, const simplyp_dims* dims, const simp
     } while (0)
             if (opts->integrator == SIMPLYP_INTEG_CASHKARP) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP, 1);
             else if (opts->integrator == SIMPLYP_INTEG_CASHKARP_AUG_F32) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG_F32, 1);
+            else if (stiff) {
+#define SIMPLYP_LAUNCH_QUEUE_STIFF(TEAM)                                                                                                                 \
+    do {                                                                                                                                                 \
+        if (snow) hipLaunchKernelGGL((simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG, true, TEAM, true>), dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);  \
+        else hipLaunchKernelGGL((simplyp::simplyp_queue_kernel<SIMPLYP_INTEG_CASHKARP_AUG, false, TEAM, true>), dim3(workers), dim3(simplyp::WAVE), 0, ctx->stream, k, q);      \
+    } while (0)
+                if (team == 4) SIMPLYP_LAUNCH_QUEUE_STIFF(4); else SIMPLYP_LAUNCH_QUEUE_STIFF(1);
+#undef SIMPLYP_LAUNCH_QUEUE_STIFF
+            }
             else if (team == 4) SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG, 4);
             else SIMPLYP_LAUNCH_QUEUE(SIMPLYP_INTEG_CASHKARP_AUG, 1);
 #undef SIMPLYP_LAUNCH_QUEUE
@@ -1080,6 +1102,7 @@ static int sync_impl(simplyp_ctx* ctx, simplyp_stats* stats)
         stats->queued = ctx->queued;
         stats->lanes_per_wave = ctx->lanes;
         stats->lanes_per_member = ctx->team;
+        stats->stiff_pair = ctx->stiff;
         stats->streamed_chunks = copied ? ctx->streamed_chunks : 0;
         stats->d2h_tail_ms = copied ? ms_tail : 0.0;
         stats->stream_gbs = stream_gbs;

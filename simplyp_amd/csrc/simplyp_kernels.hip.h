@@ -508,11 +508,34 @@ struct SysAugF {
 // with a zero step until the slowest lane of the wavefront is done.
 struct CkCounters { unsigned rhs, steps, rejected, wave_trips; bool capped, poisoned; };
 
-template <class SYS>
+// The tableau(s) in LDS, for the instantiations that switch pairs lane by lane (STIFF, opts.stiff_pair): row 0 Cash-Karp, row 1 the
+// stability-optimised 4(3) pair of include/simplyp_controller.h (same sparsity: 15 a, 4 b, 5 e).  A lane reads its coefficients
+// through a per-lane row offset; rows are TAB_STRIDE doubles apart so that the two rows of a coefficient sit in different banks.
+constexpr int TAB_STRIDE = 26;
+enum { TA21 = 0, TA31, TA32, TA41, TA42, TA43, TA51, TA52, TA53, TA54, TA61, TA62, TA63, TA64, TA65,
+       TB1, TB3, TB4, TB6, TE1, TE3, TE4, TE5, TE6, TAB_N };
+__device__ __forceinline__ void tableau_to_lds(double* s_tab, int lane)
+{
+    const double ck[TAB_N] = {1.0 / 5, 3.0 / 40, 9.0 / 40, 3.0 / 10, -9.0 / 10, 6.0 / 5, -11.0 / 54, 5.0 / 2, -70.0 / 27, 35.0 / 27,
+                              1631.0 / 55296, 175.0 / 512, 575.0 / 13824, 44275.0 / 110592, 253.0 / 4096,
+                              37.0 / 378, 250.0 / 621, 125.0 / 594, 512.0 / 1771,
+                              37.0 / 378 - 2825.0 / 27648, 250.0 / 621 - 18575.0 / 48384, 125.0 / 594 - 13525.0 / 55296, -277.0 / 14336,
+                              512.0 / 1771 - 1.0 / 4};
+    const double st[TAB_N] = {SIMPLYP_STIFF_A21, SIMPLYP_STIFF_A31, SIMPLYP_STIFF_A32, SIMPLYP_STIFF_A41, SIMPLYP_STIFF_A42, SIMPLYP_STIFF_A43,
+                              SIMPLYP_STIFF_A51, SIMPLYP_STIFF_A52, SIMPLYP_STIFF_A53, SIMPLYP_STIFF_A54,
+                              SIMPLYP_STIFF_A61, SIMPLYP_STIFF_A62, SIMPLYP_STIFF_A63, SIMPLYP_STIFF_A64, SIMPLYP_STIFF_A65,
+                              SIMPLYP_STIFF_B1, SIMPLYP_STIFF_B3, SIMPLYP_STIFF_B4, SIMPLYP_STIFF_B6,
+                              SIMPLYP_STIFF_E1, SIMPLYP_STIFF_E3, SIMPLYP_STIFF_E4, SIMPLYP_STIFF_E5, SIMPLYP_STIFF_E6};
+    if (lane < TAB_N) { s_tab[lane] = ck[lane]; s_tab[TAB_STRIDE + lane] = st[lane]; }
+    __syncthreads();
+}
+
+template <class SYS, bool STIFF = false, bool LATE_FETCH = false>
 __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double (&yq)[4], const typename SYS::dayconst& c,
                                        const double T_, const double rtol_, const double atol_, int max_steps, double& h_carry,
-                                       CkCounters& cnt, const bool lane_active)
+                                       CkCounters& cnt, const bool lane_active, const double* s_tab = nullptr)
 {
+    static_assert(!STIFF || SYS::KINK_AWARE, "the second pair exists for the knee-aware fp64 scheme only");
     typedef typename SYS::real R;       // working precision of the stages (the daily integrals yq stay fp64)
     constexpr int NS = SYS::NS;
     const R T = (R)T_, rtol = (R)rtol_, atol = (R)atol_;
@@ -531,14 +554,22 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     // one wave per SIMD, where every scalar instruction costs a full slot (tools/micro/valu_rates.hip: 2.6 ns, the price of
     // an fp64 FMA).  Passing the values through an empty asm with an "s" operand makes them opaque: -1.4 % kernel time.
 #define SP_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
+    if constexpr (!STIFF) {
     SP_KEEP_SCALAR(a21); SP_KEEP_SCALAR(a31); SP_KEEP_SCALAR(a32); SP_KEEP_SCALAR(a41); SP_KEEP_SCALAR(a42); SP_KEEP_SCALAR(a43);
     SP_KEEP_SCALAR(a51); SP_KEEP_SCALAR(a52); SP_KEEP_SCALAR(a53); SP_KEEP_SCALAR(a54);
     SP_KEEP_SCALAR(a61); SP_KEEP_SCALAR(a62); SP_KEEP_SCALAR(a63); SP_KEEP_SCALAR(a64); SP_KEEP_SCALAR(a65);
     SP_KEEP_SCALAR(b1); SP_KEEP_SCALAR(b3); SP_KEEP_SCALAR(b4); SP_KEEP_SCALAR(b6);
     SP_KEEP_SCALAR(e1); SP_KEEP_SCALAR(e3); SP_KEEP_SCALAR(e4); SP_KEEP_SCALAR(e5); SP_KEEP_SCALAR(e6);
+    }
     R huge = sp_huge<R>(), c11 = (R)1.1;
     SP_KEEP_SCALAR(huge); SP_KEEP_SCALAR(c11);
 #undef SP_KEEP_SCALAR
+    // STIFF: a coefficient is read from this lane's row of the LDS table (row offset toff, set once the attempt's pair is known); else the
+    // SGPR constant
+    // (an integer row offset into the __shared__ table, not a pointer: a selected / laundered pointer loses its address space and
+    // the reads become flat loads with a full wait behind each)
+#define TC(name, idx) (STIFF ? (R)s_tab[toff + (idx)] : name)
+    int toff = 0;
     R t = 0, h = (R)h_carry;
     // (the step size carried over the day boundary belongs to the smooth end of a day; the forcing jumps at midnight, and the
     // first attempt of the new day with it was rejected on 85 % of the member-days: SYS::DAY_START of it is the better guess)
@@ -577,15 +608,24 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         hh = (rem <= c11 * h) ? rem : hh;
         const bool last_chance = (trip + 1 >= max_steps);
         if (last_chance) hh = rem;
+        if constexpr (STIFF) {
+            // (opts.stiff_pair) no attempt reaches further than SIMPLYP_STIFF_CAP relaxation times of the reach; the rate is the carried
+            // state y[9] = cQ Qr**b_Q itself
+            const R hcap = (R)SIMPLYP_STIFF_CAP * sp_rcp1(y[9]);
+            hh = (!last_chance && hh > hcap) ? hcap : hh;
+        }
         if (!alive) hh = 0;
 
         R k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], kq[4], yt[NS];
         R sq[4], eq[4];                          // sum b_s kq_s, sum e_s kq_s
         // stage weights premultiplied by the step (per lane): one FMA per (component, earlier stage)
         SYS::f(y, c, k1, kq);
+        if constexpr (!STIFF) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sq[i] = b1 * kq[i]; if (SYS::QUAD_IN_NORM) eq[i] = e1 * kq[i]; }
+        }
         bool targeted = false;
+        bool stiff = false;      // this attempt is taken by the stability-optimised pair (STIFF only)
         R kfac = (R)1;       // factor on the error estimate of a step that crosses a knee of a gate (SYS::KINK_AWARE)
         if constexpr (SYS::KINK_AWARE) {
             // times to the knees of the gates along the first slope (SYS::KNEE_*, KINK_*): soil boxes (hs), groundwater (hg)
@@ -617,32 +657,47 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
             kfac = gw ? (targeted ? (R)SYS::KNEE_GW : (R)SYS::KINK_GW) : ((cs && !targeted) ? (R)SYS::KINK_SOIL : (R)1);
             // expansive reach: the estimate of a step that starts there is multiplied by EXPAND
             kfac = kfac * ((c.bQ * k1[3] > y[3] * y[9]) ? (R)SYS::EXPAND : (R)1);
+            if constexpr (STIFF) {
+                // Which pair takes this attempt (oracle: erk_aug_day): Cash-Karp unless the step is longer than SIMPLYP_STIFF_Z_ON relaxation
+                // times of the reach -- then the second pair, except for an attempt with a knee within reach or aimed at one (what the knee
+                // rules were tuned on is Cash-Karp's estimate): that one is shortened to Cash-Karp's stability interval instead.  The choice
+                // depends on the lane's own state only.
+                const bool longstep = hh * y[9] > (R)SIMPLYP_STIFF_Z_ON;
+                const bool kneeish = cs || gw || targeted;
+                stiff = longstep && !kneeish;
+                const R hz = (R)SIMPLYP_STIFF_Z_ON * sp_rcp1(y[9]);
+                hh = (longstep && kneeish && !last_chance && alive) ? hz : hh;
+                toff = stiff ? TAB_STRIDE : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sq[i] = TC(b1, TB1) * kq[i];
+            }
         }
         {
-            const R h21 = hh * a21;
+            const R h21 = hh * TC(a21, TA21);
 #pragma unroll
             for (int i = 0; i < NS; ++i) yt[i] = sp_fma(h21, k1[i], y[i]);
         }
         SYS::f(yt, c, k2, kq);
         {
-            const R h31 = hh * a31, h32 = hh * a32;
+            const R h31 = hh * TC(a31, TA31), h32 = hh * TC(a32, TA32);
 #pragma unroll
             for (int i = 0; i < NS; ++i) yt[i] = sp_fma(h32, k2[i], sp_fma(h31, k1[i], y[i]));
         }
         SYS::f(yt, c, k3, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(b3, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e3, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(TC(b3, TB3), kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e3, kq[i], eq[i]); }
         {
-            const R h41 = hh * a41, h42 = hh * a42, h43 = hh * a43;
+            const R h41 = hh * TC(a41, TA41), h42 = hh * TC(a42, TA42), h43 = hh * TC(a43, TA43);
 #pragma unroll
             for (int i = 0; i < NS; ++i)
                 yt[i] = sp_fma(h43, k3[i], sp_fma(h42, k2[i], sp_fma(h41, k1[i], y[i])));
         }
         SYS::f(yt, c, k4, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(b4, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e4, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(TC(b4, TB4), kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e4, kq[i], eq[i]); }
+        if constexpr (STIFF && LATE_FETCH) asm volatile("" : "+v"(toff));      // (the coefficients of stages 5 and 6 are fetched from here on: see below)
         {
-            const R h51 = hh * a51, h52 = hh * a52, h53 = hh * a53, h54 = hh * a54;
+            const R h51 = hh * TC(a51, TA51), h52 = hh * TC(a52, TA52), h53 = hh * TC(a53, TA53), h54 = hh * TC(a54, TA54);
 #pragma unroll
             for (int i = 0; i < NS; ++i)
                 yt[i] = sp_fma(h54, k4[i], sp_fma(h53, k3[i], sp_fma(h52, k2[i], sp_fma(h51, k1[i], y[i]))));
@@ -651,7 +706,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e5, kq[i], eq[i]);
         {
-            const R h61 = hh * a61, h62 = hh * a62, h63 = hh * a63, h64 = hh * a64, h65 = hh * a65;
+            const R h61 = hh * TC(a61, TA61), h62 = hh * TC(a62, TA62), h63 = hh * TC(a63, TA63), h64 = hh * TC(a64, TA64), h65 = hh * TC(a65, TA65);
 #pragma unroll
             for (int i = 0; i < NS; ++i)
                 yt[i] = sp_fma(h65, k5[i], sp_fma(h64, k4[i], sp_fma(h63, k3[i],
@@ -659,13 +714,19 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         }
         SYS::f(yt, c, k6, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(b6, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e6, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(TC(b6, TB6), kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e6, kq[i], eq[i]); }
 
         // embedded error estimate and scaled error norm.  The scale uses the Euler predictor y + h k1 for "the new value":
         // the 5th-order increment itself is only formed once the step is accepted (weights premultiplied by the accept mask).
         R err = 0, chk = 0;
         R dq[4];
-        const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
+        if constexpr (STIFF && LATE_FETCH) {
+            // (the snow instantiations, which carry a few more live values:) the error and update weights are fetched HERE, not together
+            // with the stage coefficients at the top of the attempt: held from there they are 18 more VGPRs at the loop's peak (all six
+            // stage derivatives live), which spilled 20 B per lane to scratch in simplyp_chain_kernel<2, true, 1, true>
+            asm volatile("" : "+v"(toff));
+        }
+        const R he1 = hh * TC(e1, TE1), he3 = hh * TC(e3, TE3), he4 = hh * TC(e4, TE4), he5 = hh * TC(e5, TE5), he6 = hh * TC(e6, TE6);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             if (i < SYS::N_ERR) {
@@ -705,7 +766,9 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         // err == inf gives 0 -> 0.2 (err is never NaN: v_max_f64 drops NaNs).
         // (raw v_log_f32 / v_exp_f32: the library versions add denormal-range fix-ups, ~12 instructions, for arguments
         // whose factor is clamped to 5 anyway)
-        float fac = (float)SIMPLYP_CTRL_SAFETY * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
+        // (an attempt of the second pair carries a third-order estimate: exponent -1/4)
+        const float fexp = (STIFF && stiff) ? (float)SIMPLYP_STIFF_ERR_EXP : -0.2f;
+        float fac = (float)SIMPLYP_CTRL_SAFETY * __builtin_amdgcn_exp2f(fexp * __builtin_amdgcn_logf((float)err));
         fac = fminf(fmaxf(fac, (float)SIMPLYP_CTRL_FAC_MIN), (float)SIMPLYP_CTRL_FAC_MAX);
         const bool accept = alive && !bad && (err <= (R)1 || last_chance);
         bool give_up = false;
@@ -731,7 +794,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         }
         {
             const R m = accept ? hh : (R)0;
-            const R hb1 = m * b1, hb3 = m * b3, hb4 = m * b4, hb6 = m * b6;
+            const R hb1 = m * TC(b1, TB1), hb3 = m * TC(b3, TB3), hb4 = m * TC(b4, TB4), hb6 = m * TC(b6, TB6);
 #pragma unroll
             for (int i = 0; i < NS; ++i) y[i] = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], sp_fma(hb1, k1[i], y[i]))));
             const R mq = accept ? (R)1 : (R)0;
@@ -768,6 +831,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     cnt.steps += n_acc;
     cnt.rejected += n_alive - n_acc - (gave_up_today ? 1u : 0u);
     h_carry = (double)h;
+#undef TC
 }
 
 // ---------------------------------------------------------------------------------------
@@ -904,9 +968,10 @@ __device__ __forceinline__ void quad_rhs(const double (&x)[3], const QuadConst& 
 // ck_day<SysAug> for a quad.  z[7] (the physical states VsA VsS Vg Qr Msus TDPr PPr) and yq[4] hold the member's state on every
 // lane of the quad, on entry and on return; aux1 is THIS lane's carried function for the day's start (lane 0: exp(-mu VsA),
 // 1: exp(-mu VsS), 2: Qr**k_M, 3: cQ Qr**b_Q -- evaluated by run_slot at the day boundary, one exponential per lane).
+template <bool STIFF = false>
 __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, double (&yq)[4], const DayConst& c,
                                             const double T, const double rtol, const double atol, int max_steps, double& h_carry,
-                                            CkCounters& cnt, const bool lane_active, const int j)
+                                            CkCounters& cnt, const bool lane_active, const int j, const double* s_tab = nullptr)
 {
     typedef double R;
     const bool j_lt2 = j < 2, j_eq2 = j == 2, j_eq3 = j == 3;
@@ -921,14 +986,18 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
     R e1 = 37.0 / 378 - 2825.0 / 27648, e3 = 250.0 / 621 - 18575.0 / 48384,
       e4 = 125.0 / 594 - 13525.0 / 55296, e5 = -277.0 / 14336, e6 = 512.0 / 1771 - 1.0 / 4;
 #define SP_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
+    if constexpr (!STIFF) {
     SP_KEEP_SCALAR(a21); SP_KEEP_SCALAR(a31); SP_KEEP_SCALAR(a32); SP_KEEP_SCALAR(a41); SP_KEEP_SCALAR(a42); SP_KEEP_SCALAR(a43);
     SP_KEEP_SCALAR(a51); SP_KEEP_SCALAR(a52); SP_KEEP_SCALAR(a53); SP_KEEP_SCALAR(a54);
     SP_KEEP_SCALAR(a61); SP_KEEP_SCALAR(a62); SP_KEEP_SCALAR(a63); SP_KEEP_SCALAR(a64); SP_KEEP_SCALAR(a65);
     SP_KEEP_SCALAR(b1); SP_KEEP_SCALAR(b3); SP_KEEP_SCALAR(b4); SP_KEEP_SCALAR(b6);
     SP_KEEP_SCALAR(e1); SP_KEEP_SCALAR(e3); SP_KEEP_SCALAR(e4); SP_KEEP_SCALAR(e5); SP_KEEP_SCALAR(e6);
+    }
     R huge = sp_huge<R>(), c11 = (R)1.1;
     SP_KEEP_SCALAR(huge); SP_KEEP_SCALAR(c11);
 #undef SP_KEEP_SCALAR
+#define TC(name, idx) (STIFF ? s_tab[toff + (idx)] : name)
+    int toff = 0;
     R t = 0, h = (R)h_carry * SysAug::DAY_START;
     if (!(h > (R)0) || h > T) h = T;
     int trip = 0;
@@ -968,13 +1037,19 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
         hh = (rem <= c11 * h) ? rem : hh;
         const bool last_chance = (trip + 1 >= max_steps);
         if (last_chance) hh = rem;
+        if constexpr (STIFF) {
+            // ck_day<SysAug, true>'s cap: the reach lane holds the rate cQ Qr**b_Q (its slot 1)
+            const R hcap = quad_bcast<3>(SIMPLYP_STIFF_CAP * sp_rcp1(y[1]));
+            hh = (!last_chance && hh > hcap) ? hcap : hh;
+        }
         if (!alive) hh = 0;
 
         R k1[3], k2[3], k3[3], k4[3], k5[3], k6[3], kq, yt[3];
         R sq;
         quad_rhs(y, k, j_lt2, j_eq2, k1, kq);
-        sq = b1 * kq;
+        if constexpr (!STIFF) sq = b1 * kq;
         bool targeted = false;
+        bool kneeish = false, stiff = false;
         R kfac = 1.0;
         // Knee logic of ck_day<SysAug>, with a wave-uniform shortcut in front.  This lane's gate argument moves along the first
         // slope as g(t) = g + sl t; it has a knee (g = 0 or g = gd) at a time in (a, b) exactly when g(a) and g(b), or g(a) - gd
@@ -1013,54 +1088,64 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
             kink |= __builtin_amdgcn_update_dpp(0, kink, SP_QP(2, 3, 0, 1), 0xf, 0xf, true);
             const bool gw = (kink & 2) != 0 || (kink & 5) == 5;
             kfac = gw ? (targeted ? SysAug::KNEE_GW : SysAug::KINK_GW) : (((kink & 1) && !targeted) ? SysAug::KINK_SOIL : 1.0);
+            kneeish = (kink & 1) != 0 || gw || targeted;
         }
         {
             // expansive reach (SysAug::EXPAND): the reach lane holds Qr, cQ Qr**b_Q and the first slope of Qr; its verdict goes to the quad
             const int expanding = __builtin_amdgcn_update_dpp(0, (k.c1 * k1[0] > y[0] * y[1]) ? 1 : 0, SP_QP(3, 3, 3, 3), 0xf, 0xf, true);
             kfac = kfac * (expanding ? SysAug::EXPAND : 1.0);
         }
+        if constexpr (STIFF) {
+            // ck_day<SysAug, true>'s choice of the pair, from the reach lane's rate (same operations: bit-identical decisions)
+            const bool longstep = quad_bcast<3>(hh * y[1]) > SIMPLYP_STIFF_Z_ON;
+            stiff = longstep && !kneeish;
+            const R hz = quad_bcast<3>(SIMPLYP_STIFF_Z_ON * sp_rcp1(y[1]));
+            hh = (longstep && kneeish && !last_chance && alive) ? hz : hh;
+            toff = stiff ? TAB_STRIDE : 0;
+            sq = TC(b1, TB1) * kq;
+        }
         {
-            const R h21 = hh * a21;
+            const R h21 = hh * TC(a21, TA21);
 #pragma unroll
             for (int i = 0; i < 3; ++i) yt[i] = sp_fma(h21, k1[i], y[i]);
         }
         quad_rhs(yt, k, j_lt2, j_eq2, k2, kq);
         {
-            const R h31 = hh * a31, h32 = hh * a32;
+            const R h31 = hh * TC(a31, TA31), h32 = hh * TC(a32, TA32);
 #pragma unroll
             for (int i = 0; i < 3; ++i) yt[i] = sp_fma(h32, k2[i], sp_fma(h31, k1[i], y[i]));
         }
         quad_rhs(yt, k, j_lt2, j_eq2, k3, kq);
-        sq = sp_fma(b3, kq, sq);
+        sq = sp_fma(TC(b3, TB3), kq, sq);
         {
-            const R h41 = hh * a41, h42 = hh * a42, h43 = hh * a43;
+            const R h41 = hh * TC(a41, TA41), h42 = hh * TC(a42, TA42), h43 = hh * TC(a43, TA43);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 yt[i] = sp_fma(h43, k3[i], sp_fma(h42, k2[i], sp_fma(h41, k1[i], y[i])));
         }
         quad_rhs(yt, k, j_lt2, j_eq2, k4, kq);
-        sq = sp_fma(b4, kq, sq);
+        sq = sp_fma(TC(b4, TB4), kq, sq);
         {
-            const R h51 = hh * a51, h52 = hh * a52, h53 = hh * a53, h54 = hh * a54;
+            const R h51 = hh * TC(a51, TA51), h52 = hh * TC(a52, TA52), h53 = hh * TC(a53, TA53), h54 = hh * TC(a54, TA54);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 yt[i] = sp_fma(h54, k4[i], sp_fma(h53, k3[i], sp_fma(h52, k2[i], sp_fma(h51, k1[i], y[i]))));
         }
         quad_rhs(yt, k, j_lt2, j_eq2, k5, kq);
         {
-            const R h61 = hh * a61, h62 = hh * a62, h63 = hh * a63, h64 = hh * a64, h65 = hh * a65;
+            const R h61 = hh * TC(a61, TA61), h62 = hh * TC(a62, TA62), h63 = hh * TC(a63, TA63), h64 = hh * TC(a64, TA64), h65 = hh * TC(a65, TA65);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 yt[i] = sp_fma(h65, k5[i], sp_fma(h64, k4[i], sp_fma(h63, k3[i],
                         sp_fma(h62, k2[i], sp_fma(h61, k1[i], y[i])))));
         }
         quad_rhs(yt, k, j_lt2, j_eq2, k6, kq);
-        sq = sp_fma(b6, kq, sq);
+        sq = sp_fma(TC(b6, TB6), kq, sq);
 
         // error norm over the 7 physical states = slots 0 and 2 of the quad (lane 3's slot 2 is identically 0 and adds
         // nothing); the maximum over the quad is exact in any order.  The finiteness test looks at the increments of the reach
         // states (Qr, Msus, TDPr, PPr), as ck_day<SysAug>'s `chk` does: a non-finite one makes the lane's error infinite.
-        const R he1 = hh * e1, he3 = hh * e3, he4 = hh * e4, he5 = hh * e5, he6 = hh * e6;
+        const R he1 = hh * TC(e1, TE1), he3 = hh * TC(e3, TE3), he4 = hh * TC(e4, TE4), he5 = hh * TC(e5, TE5), he6 = hh * TC(e6, TE6);
         R err = 0;
         R he_s[3];
 #pragma unroll
@@ -1092,7 +1177,8 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
         const bool bad = !(err < huge);
 
         ++trip;
-        float fac = (float)SIMPLYP_CTRL_SAFETY * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
+        const float fexp = (STIFF && stiff) ? (float)SIMPLYP_STIFF_ERR_EXP : -0.2f;
+        float fac = (float)SIMPLYP_CTRL_SAFETY * __builtin_amdgcn_exp2f(fexp * __builtin_amdgcn_logf((float)err));
         fac = fminf(fmaxf(fac, (float)SIMPLYP_CTRL_FAC_MIN), (float)SIMPLYP_CTRL_FAC_MAX);
         const bool accept = alive && !bad && (err <= (R)1 || last_chance);
         bool give_up = false;
@@ -1112,7 +1198,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
         }
         {
             const R m = accept ? hh : (R)0;
-            const R hb1 = m * b1, hb3 = m * b3, hb4 = m * b4, hb6 = m * b6;
+            const R hb1 = m * TC(b1, TB1), hb3 = m * TC(b3, TB3), hb4 = m * TC(b4, TB4), hb6 = m * TC(b6, TB6);
 #pragma unroll
             for (int i = 0; i < 3; ++i) y[i] = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], sp_fma(hb1, k1[i], y[i]))));
             const R mq = accept ? (R)1 : (R)0;
@@ -1151,6 +1237,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
     z[0] = quad_bcast<0>(y[0]); z[1] = quad_bcast<1>(y[0]); z[2] = quad_bcast<2>(y[0]); z[3] = quad_bcast<3>(y[0]);
     z[4] = quad_bcast<0>(y[2]); z[5] = quad_bcast<1>(y[2]); z[6] = quad_bcast<2>(y[2]);
     yq[0] = quad_bcast<3>(yqv); yq[1] = quad_bcast<0>(yqv); yq[2] = quad_bcast<1>(yqv); yq[3] = quad_bcast<2>(yqv);
+#undef TC
 }
 #undef SP_QP
 
@@ -1204,11 +1291,12 @@ __device__ __forceinline__ void soil_p_update(double aP, double KfMsoil, double 
 // kernel (single-reach problems); the chain kernel passes nullptr and runs all days of every reach.
 constexpr int CKPT_N = 16;    // y[8], Plab_A, TDPs_A, Plab_NC, TDPs_NC, conc_A, conc_NC, h_carry, snow depth
 
-template <int INTEG, bool SNOW, int TEAM>
+template <int INTEG, bool SNOW, int TEAM, bool STIFF = false>
 __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, double* s_E, double* s_T, int* s_doy,
                                          const int lane, const int slot_raw, const int* reaches, const int n_reaches,
-                                         const int d_begin, const int d_end, double* ckpt)
+                                         const int d_begin, const int d_end, double* ckpt, const double* s_tab = nullptr)
 {
+    static_assert(!STIFF || INTEG == SIMPLYP_INTEG_CASHKARP_AUG, "the second pair (opts.stiff_pair) exists for integrator 2 only");
     static_assert(TEAM == 1 || (TEAM == 4 && INTEG == SIMPLYP_INTEG_CASHKARP_AUG), "four lanes per member: scheme 2 only");
     const bool active = slot_raw < a.E;
     // TEAM == 4: the four lanes of a quad share a member slot.  Everything outside the day's integration (day constants, soil P,
@@ -1498,13 +1586,13 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                     if (TEAM == 4) {
                         double z[7];
                         z[0] = y[0]; z[1] = y[1]; z[2] = y[2]; z[3] = y[4]; z[4] = y[5]; z[5] = y[6]; z[6] = y[7];
-                        ck_day_quad(z, aux[0], yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active, qj);
+                        ck_day_quad<STIFF>(z, aux[0], yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active, qj, s_tab);
                         y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
                     } else {
                         double z[11];
                         z[0] = y[0]; z[1] = y[1]; z[2] = y[2]; z[3] = y[4]; z[4] = y[5]; z[5] = y[6]; z[6] = y[7];
                         z[7] = aux[0]; z[8] = aux[1]; z[9] = aux[2]; z[10] = aux[3];
-                        ck_day<SysAug>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active);
+                        ck_day<SysAug, STIFF, SNOW>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active, s_tab);
                         y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
                     }
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
@@ -1644,13 +1732,15 @@ __device__ __forceinline__ int slot_of_lane(const KernelArgs& a, int group, int 
 // (tools/micro/valu_rates.hip, profiles/r02_valu_rates.log), while fitting two waves (256 registers each, with the fp64 day-level
 // state beside the float stages) spilled 712 B per lane to scratch and ran 22 % slower (profiles/r02_experiments.md).  What
 // makes BASELINE config C5 fast is its tolerance (44 instead of 84 right-hand sides per catchment-day), not the fp32 rate.
-template <int INTEG, bool SNOW, int TEAM>
+template <int INTEG, bool SNOW, int TEAM, bool STIFF = false>
 __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs a)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
     __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
+    __shared__ double s_tab[STIFF ? 2 * TAB_STRIDE : 1];
+    if (STIFF) tableau_to_lds(s_tab, threadIdx.x);
     const int c0 = a.chain_ptr[blockIdx.y], c1 = a.chain_ptr[blockIdx.y + 1];
     if (a.win_stride > 0) {      // pilot windows: the same short run over different stretches of the forcing
         KernelArgs w = a;
@@ -1659,10 +1749,10 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_chain_kernel(const KernelArgs
         w.doy = a.doy ? a.doy + off : nullptr;
         w.member_rhs = a.member_rhs + (size_t)blockIdx.z * a.E;
         w.route = a.route ? a.route + (size_t)blockIdx.z * a.win_route_stride : nullptr;
-        run_slot<INTEG, SNOW, TEAM>(w, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+        run_slot<INTEG, SNOW, TEAM, STIFF>(w, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr, s_tab);
         return;
     }
-    run_slot<INTEG, SNOW, TEAM>(a, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr);
+    run_slot<INTEG, SNOW, TEAM, STIFF>(a, s_P, s_E, s_T, s_doy, threadIdx.x, slot_of_lane(a, blockIdx.x, threadIdx.x), a.chain_reach + c0, c1 - c0, 0, a.D, nullptr, s_tab);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1751,13 +1841,15 @@ __device__ __forceinline__ unsigned queue_take_ticket(const QueueArgs& q, int la
 
 // The persistent loop has a single exit, at its head, on a scalar: with `break`s in the body hipcc (ROCm 7.2)
 // structurised the ticket loop into a lane-masked inner loop that re-ran task 0 forever.
-template <int INTEG, bool SNOW, int TEAM>
+template <int INTEG, bool SNOW, int TEAM, bool STIFF = false>
 __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs a, const QueueArgs q)
 {
     __shared__ double s_P[TILE_D];
     __shared__ double s_E[TILE_D];
     __shared__ double s_T[TILE_D];
     __shared__ int s_doy[TILE_D];
+    __shared__ double s_tab[STIFF ? 2 * TAB_STRIDE : 1];
+    if (STIFF) tableau_to_lds(s_tab, threadIdx.x);
     const int lane = threadIdx.x;
     const unsigned G = (unsigned)q.n_groups;
     const unsigned n_tasks = (unsigned)q.n_pairs * G;
@@ -1779,8 +1871,8 @@ __global__ __launch_bounds__(WAVE, 1) void simplyp_queue_kernel(const KernelArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int d_begin = c * q.chunk_days;
             const int d_end = min(a.D, d_begin + q.chunk_days);
-            run_slot<INTEG, SNOW, TEAM>(a, s_P, s_E, s_T, s_doy, lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
-                            q.ckpt + (size_t)s * CKPT_N * (size_t)a.E);
+            run_slot<INTEG, SNOW, TEAM, STIFF>(a, s_P, s_E, s_T, s_doy, lane, slot_of_lane(a, g, lane), q.task_reach + pair, 1, d_begin, d_end,
+                                   q.ckpt + (size_t)s * CKPT_N * (size_t)a.E, s_tab);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -832,3 +832,45 @@ def test_default_solver_in_the_dry_reach_regime_against_the_reference(engine0, l
     assert st.max() == 0 and stats['lanes_per_member'] == lanes
     worst = helpers.dry_worst_per_member(got, tables, marshal.OUT_COLUMNS)
     assert max(worst) < 1e-6, dict(zip(m['members'], worst))
+
+
+@pytest.mark.parametrize('lanes', [1, 4])
+def test_second_pair_on_a_stiff_reach_chain(engine0, oracle_lib, lanes):
+    """opts.stiff_pair on the device (ck_day<SysAug, true>, ck_day_quad<true>): attempts bound by Cash-Karp's stability interval go, lane
+    by lane, to the stability-optimised 4(3) pair.  Config C4's chain (256 reaches, 16 members, 300 days): auto = on for a network; a
+    fifth fewer right-hand sides than Cash-Karp alone, both within the bar against the converged solution; kernel == oracle (same rule,
+    same counts up to accept/reject flips); one lane == four lanes bit for bit."""
+    pr = synthetic.c4_problem(16, n_reaches=256, n_days=300, solver=dict(lanes_per_member=lanes))
+
+    def run(stiff, rtol=None, atol=None, n_lanes=lanes):
+        o = pr['opts']
+        r0, a0 = o.rtol, o.atol
+        if rtol:
+            o.rtol, o.atol = rtol, atol
+        o.stiff_pair, o.lanes_per_member = stiff, n_lanes
+        try:
+            out, status, stats = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], o,
+                                             out_reaches=pr['out_reaches'])
+        finally:
+            o.rtol, o.atol, o.stiff_pair, o.lanes_per_member = r0, a0, 0, lanes
+        assert int(status.max()) == 0 and stats['lanes_per_member'] == n_lanes
+        return out.cpu().numpy(), stats
+    truth, _ = run(-1, 1e-11, 1e-13)
+    off, s_off = run(-1)
+    on, s_on = run(1)
+    auto, s_auto = run(0)
+    assert s_off['stiff_pair'] == 0 and s_on['stiff_pair'] == 1 and s_auto['stiff_pair'] == 1
+    assert np.array_equal(auto, on, equal_nan=True) and s_auto['rhs_evals'] == s_on['rhs_evals']
+    err = lambda a: float((np.abs(a - truth) / np.maximum(np.abs(truth), 1e-300)).max())
+    assert err(off) < 5e-7 and err(on) < 5e-7, (err(off), err(on))
+    assert s_on['rhs_evals'] < 0.85 * s_off['rhs_evals'], (s_on['rhs_evals'], s_off['rhs_evals'])
+    # the CPU oracle mirrors the rule: two members of the run
+    pick = [3, 11]
+    sub = dict(pr, member_params=np.ascontiguousarray(pr['member_params'][:, pick]), reach_params=np.ascontiguousarray(pr['reach_params'][:, :, pick]))
+    sub['opts'].stiff_pair = 1
+    cref, cst, cstats = cpu_run(oracle_lib, sub, out_reaches=pr['out_reaches'], n_threads=2)
+    sub['opts'].stiff_pair = 0
+    assert cst.max() == 0 and helpers.max_rel_err(on[..., pick], cref, floor=FLOOR) < helpers.TOL_WORKING
+    if lanes == 4:        # bit-identical to the one-lane kernel, second pair included
+        one, s_one = run(1, n_lanes=1)
+        assert np.array_equal(one, on, equal_nan=True) and s_one['rhs_evals'] == s_on['rhs_evals'] and s_one['rejected'] == s_on['rejected']

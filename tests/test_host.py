@@ -316,3 +316,38 @@ def test_bench_parent_launches_its_own_ranks_without_touching_the_gpu(monkeypatc
     assert set(bench.CONFIGS) == {'c2', 'c3', 'c4', 'c5', 'strong_1m'} and bench.CONFIGS['strong_1m']['scaling'] == 'strong' and bench.CONFIGS['c2']['bytes_per_cd'] == 216.0
     assert bench.CONFIGS['c3']['bytes_per_cd'] == 56.0 and not bench.CONFIGS['c5']['parity_grade']
     assert bench.kernel_source_hash() == bench.kernel_source_hash() and len(bench.kernel_source_hash()) == 16
+
+
+def test_second_pair_coefficients_are_what_the_derivation_gives():
+    """include/simplyp_controller.h SIMPLYP_STIFF_*: the stability-optimised 4(3) pair.  The header's numbers satisfy the 8 + 4 order
+    conditions to rounding, are stable on the real axis beyond the cap the controller uses, keep every internal stage polynomial
+    bounded there -- and are exactly what tools/derive_stiff_pair.py prints for the recorded search (deterministic, ~5 s)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'include', 'simplyp_controller.h')) as fh:
+        txt = fh.read()
+    macros = {k: float(v) for k, v in re.findall(r'#define SIMPLYP_STIFF_([A-Z0-9_]+) \(?(-?[0-9.e+-]+)\)?', txt)}
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import derive_stiff_pair as d
+    x = np.zeros(27)
+    for k, nm in enumerate(d.NAMES_A):
+        x[k] = macros[nm]
+    b = np.zeros(6); e = np.zeros(6)
+    for k in (0, 2, 3, 5):
+        b[k] = macros['B%d' % (k + 1)]
+    for k in (0, 2, 3, 4, 5):
+        e[k] = macros['E%d' % (k + 1)]
+    x[15:21], x[21:27] = b, b - e
+    A, bb, bh = d.unpack(x)
+    assert np.abs(d.order4(A, bb)).max() < 1e-15 and np.abs(d.order4(A, bh)[:4]).max() < 1e-15
+    pr = d.properties(x)
+    assert pr['beta'] > 9.0 > macros['CAP'] > macros['Z_ON'] > 3.0 and pr['max_stage_poly'] < 1.51 and pr['max_Rhat'] <= 1.0 + 1e-9
+    assert macros['Z_ON'] < 3.73                       # Cash-Karp's own real stability interval: the switch happens inside it
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'derive_stiff_pair.py'), '--emit'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    derived = {k: float(v) for k, v in re.findall(r'#define SIMPLYP_STIFF_([A-Z0-9_]+) (-?[0-9.e+-]+)', out.stdout)}
+    assert set(derived) == set(macros) - {'Z_ON', 'CAP', 'ERR_EXP'}
+    for k, v in derived.items():
+        assert abs(v - macros[k]) <= 1e-15 * max(1.0, abs(v)), k

@@ -285,3 +285,42 @@ def test_oracle_default_solver_in_the_dry_reach_regime_against_the_reference(ora
     assert max(worst) < 1e-6, dict(zip(m['members'], worst))
     qr = out[marshal.OUT_COLUMNS.index('Qr')]
     assert min(float(qr[lo:hi, 0, k].min()) for k, (lo, hi, _) in enumerate(tables)) < 1e-3      # the reaches do nearly dry up
+
+
+def test_oracle_second_pair_on_a_stiff_reach_chain(oracle_lib):
+    """opts.stiff_pair (round 4): far down a reach network Cash-Karp's steps are bound by its real stability interval (|h x rate| <= 3.73,
+    rate = cQ Qr**b_Q), not by accuracy; those attempts go, lane by lane, to a stability-optimised explicit 4(3) pair of the same six
+    stages (include/simplyp_controller.h SIMPLYP_STIFF_*).  On config C4's chain (2 members, 240 days): a fifth fewer right-hand sides at
+    no loss of accuracy against the converged solution; auto = on for a network, off for a single reach."""
+    from simplyp_amd import synthetic
+    pr = synthetic.c4_problem(2, n_reaches=256, n_days=240)
+
+    def run(stiff, rtol=None, atol=None):
+        o = pr['opts']
+        r0, a0 = o.rtol, o.atol
+        if rtol:
+            o.rtol, o.atol = rtol, atol
+        o.stiff_pair = stiff
+        try:
+            out, status, stats = oracle_lib.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], o,
+                                                out_reaches=pr['out_reaches'], n_threads=4)
+        finally:
+            o.rtol, o.atol, o.stiff_pair = r0, a0, 0
+        assert status.max() == 0
+        return out, stats
+    truth, _ = run(-1, 1e-11, 1e-13)
+    off, s_off = run(-1)
+    on, s_on = run(1)
+    auto, s_auto = run(0)
+    assert np.array_equal(auto, on) and s_auto['rhs_evals'] == s_on['rhs_evals']          # a network: auto = on
+    err = lambda a: float((np.abs(a - truth) / np.maximum(np.abs(truth), 1e-300)).max())
+    assert err(off) < 5e-7 and err(on) < 5e-7 and err(on) < 1.5 * err(off), (err(off), err(on))
+    assert s_on['rhs_evals'] < 0.85 * s_off['rhs_evals'], (s_on['rhs_evals'], s_off['rhs_evals'])
+    # a single reach: auto = off (bit-identical to the round-3 solver), and on changes next to nothing there
+    m = helpers.marshal_scenario('tarland_2004_dynamic', E=1, out_mask=marshal.MASK_REACH5)
+    outs = {}
+    for sp in (0, -1, 1):
+        m['opts'].stiff_pair = sp
+        outs[sp] = oracle_lib.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])[0]
+    assert np.array_equal(outs[0], outs[-1])
+    assert helpers.max_rel_err(outs[1], outs[-1], floor=1e-300) < 1e-6

@@ -169,6 +169,7 @@ def test_snow_depth_column_needs_the_snow_module(engine0):
         sp.run_simply_p_ensemble(met.copy(), p_struc, p_SU, p_LU, p_SC, p, dyn, n_members=2, outputs=['Qr', 'D_snow'])
 
 
+@pytest.mark.gpu
 def test_snow_depth_column_together_with_goodness_of_fit_and_waterbody(engine0):
     """the 26th column's bit is outside SIMPLYP_MASK_ALL; simplyp_gof / _spearman / _waterbody used to refuse a table
     that carries it (after the whole ensemble had run).  It is the highest bit, so the offsets of Qr and the fluxes do not move:
