@@ -416,6 +416,10 @@ static void erk_aug_day(const erk_tableau* tab, const erk_tableau* stiff, double
     z[7] = exp(-p->mu * y[0]); z[8] = exp(-p->mu * y[1]);
     z[9] = pow(y[4], p->b_Q); z[10] = pow(y[4], p->k_M);
     z[11] = z[12] = z[13] = z[14] = 0.0;
+    if (stiff) {      /* opts.stiff_pair: the day's first step reaches at most SIMPLYP_STIFF_Z_START relaxation times of the reach */
+        const double rate0 = (p->a_Q * (8.64 * 10000) / ((1 - p->b_Q) * (p->L_reach))) * z[9];
+        if (h * rate0 > SIMPLYP_STIFF_Z_START) h = SIMPLYP_STIFF_Z_START / rate0;
+    }
     while (t < T) {
         double rem = T - t, hh = h;
         if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;

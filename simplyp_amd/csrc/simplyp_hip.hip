@@ -414,6 +414,8 @@ int check_args(simplyp_ctx* ctx, const simplyp_dims* dims, const simplyp_opts* o
         return fail(ctx, SIMPLYP_ERR_ARG, "lanes_per_member must be 0 (auto), 1 or 4 (got %d)", opts->lanes_per_member);
     if (opts->lanes_per_member == 4 && opts->integrator != SIMPLYP_INTEG_CASHKARP_AUG)
         return fail(ctx, SIMPLYP_ERR_ARG, "lanes_per_member = 4 exists for integrator 2 (Cash-Karp on the augmented system) only");
+    if (opts->stiff_pair > 0 && opts->integrator != SIMPLYP_INTEG_CASHKARP_AUG)
+        return fail(ctx, SIMPLYP_ERR_ARG, "stiff_pair > 0 (the stability-optimised second pair) exists for integrator 2 (Cash-Karp on the augmented system) only");
     if (!(opts->step_len > 0.0)) return fail(ctx, SIMPLYP_ERR_ARG, "step_len must be > 0");
     if (opts->sc_qr0 < 0 || opts->sc_qr0 >= dims->S) return fail(ctx, SIMPLYP_ERR_ARG, "sc_qr0 out of range");
     if (opts->out_mask == 0u || (opts->out_mask & ~(SIMPLYP_MASK_ALL | SIMPLYP_MASK_D_SNOW)) != 0u)

@@ -575,6 +575,11 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     // first attempt of the new day with it was rejected on 85 % of the member-days: SYS::DAY_START of it is the better guess)
     if constexpr (SYS::KINK_AWARE) h *= (R)SYS::DAY_START;
     if (!(h > (R)0) || h > T) h = T;
+    if constexpr (STIFF) {
+        // (opts.stiff_pair) ... and at most SIMPLYP_STIFF_Z_START relaxation times of the reach: the day opens with its transient
+        const R h0 = (R)SIMPLYP_STIFF_Z_START * sp_rcp1(y[9]);
+        h = (h > h0) ? h0 : h;
+    }
     // attempts made today by every lane that is still alive: lanes attempt in lockstep (one attempt per trip of the loop
     // below for everyone who has not finished), so one wave-uniform counter serves them all -- and the step cap and the
     // resync schedule derived from it are scalar branches
@@ -1000,6 +1005,11 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
     int toff = 0;
     R t = 0, h = (R)h_carry * SysAug::DAY_START;
     if (!(h > (R)0) || h > T) h = T;
+    if constexpr (STIFF) {
+        // ck_day<SysAug, true>'s cap on the day's first step: the reach lane's carried function is the rate cQ Qr**b_Q
+        const R h0 = quad_bcast<3>(SIMPLYP_STIFF_Z_START * sp_rcp1(aux1));
+        h = (h > h0) ? h0 : h;
+    }
     int trip = 0;
     unsigned n_alive = 0, n_acc = 0;
     bool gave_up_today = false;

@@ -131,6 +131,16 @@ def test_quad_is_chosen_for_small_ensembles_only(engine0):
     m = perturbed('tarland_2004_static', 40, out_mask=marshal.MASK_REACH5, solver=dict(lanes_per_member=3))
     with pytest.raises(engine.EngineError, match='lanes_per_member'):
         run(engine0, m)
+    # the second pair (opts.stiff_pair): integrator 2 only when asked for explicitly; auto leaves the other schemes alone
+    m = perturbed('chain4_val_2004', 40, out_mask=marshal.MASK_REACH5, solver=dict(integrator='cashkarp', stiff_pair=1))
+    with pytest.raises(engine.EngineError, match='stiff_pair'):
+        run(engine0, m)
+    m['opts'].stiff_pair = 0
+    assert run(engine0, m)[2]['stiff_pair'] == 0
+    m = perturbed('chain4_val_2004', 40, out_mask=marshal.MASK_REACH5)
+    assert run(engine0, m)[2]['stiff_pair'] == 1                              # a network under the default solver: auto = on
+    m = perturbed('tarland_2004_static', 40, out_mask=marshal.MASK_REACH5)
+    assert run(engine0, m)[2]['stiff_pair'] == 0                              # a single reach: auto = off
 
 
 def test_quad_on_the_monte_carlo_distribution_against_the_oracle(engine0, oracle_lib):
