@@ -348,6 +348,7 @@ def test_second_pair_coefficients_are_what_the_derivation_gives():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'derive_stiff_pair.py'), '--emit'], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-500:]
     derived = {k: float(v) for k, v in re.findall(r'#define SIMPLYP_STIFF_([A-Z0-9_]+) (-?[0-9.e+-]+)', out.stdout)}
-    assert set(derived) == set(macros) - {'Z_ON', 'CAP', 'ERR_EXP'}
+    assert set(derived) == set(macros) - {'Z_ON', 'CAP', 'ERR_EXP', 'Z_START'}
+    assert 0.0 < macros['Z_START'] < 1.0
     for k, v in derived.items():
         assert abs(v - macros[k]) <= 1e-15 * max(1.0, abs(v)), k
