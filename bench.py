@@ -211,7 +211,7 @@ class Bench(object):
                 dist.init_process_group(self.backend)
         from simplyp_amd import engine
         # staging buffers next to the GPU's PCIe root: page-locked memory is placed by first touch, and a 44 GB buffer on the
-        # other socket costs a fifth of the D2H rate (44.8 instead of 55.9 GB/s: tools/probe_d2h_numa.py) -- also with one rank,
+        # other socket costs a fifth of the D2H rate (44.8 instead of 55.9 GB/s: profiles/r02_experiments.md) -- also with one rank,
         # which the scheduler may have started on either socket.  The binding is undone before the CPU baseline runs.
         try:
             self.affinity0 = os.sched_getaffinity(0)
@@ -374,8 +374,9 @@ class Leg(object):
         return float(self.e_local) * self.S * self.D
 
     def kernel_name(self, stats):
-        return "simplyp_%s_kernel<%d, false, %d>" % ("queue" if stats.get('queued') else "chain", self.opts.integrator,
-                                                     int(stats.get('lanes_per_member', 1) or 1))
+        return "simplyp_%s_kernel<%d, false, %d, %s>" % ("queue" if stats.get('queued') else "chain", self.opts.integrator,
+                                                         int(stats.get('lanes_per_member', 1) or 1),
+                                                         'true' if stats.get('stiff_pair') else 'false')
 
     def roofline_frac(self, k_ms):
         return self.cfg['bytes_per_cd'] * self.cd_rank / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
