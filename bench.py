@@ -576,6 +576,8 @@ def leg_secondary(b, config, steps=3, warmup=1):
         if config != 'c2' and not b.args.no_parity:      # (c2: every member is the base member, which parity.golden pins to the reference)
             b.progress("secondary %s: sample of the benchmarked table against the CPU oracle" % config)
             d["parity"] = sample_vs_oracle(config, leg.prob, leg.opts, leg.out, leg.host_out, stats, leg.e_local)
+            if config == 'c4':
+                d["parity"]["golden_stiff_chain"] = golden_stiff_chain(b.eng, leg.opts)
         if config == 'c2':
             d["replicas_bit_identical"] = bool((leg.out == leg.out[..., :1]).all().item())
             if leg.host_out is not None:
@@ -787,6 +789,30 @@ def parity_golden(eng, opts):
                               "against": "the unmodified reference, odeint rtol=atol=1e-12, on a climate with 0.6 x Tarland's precipitation: "
                                          "reaches that nearly dry up and are wetted again (tests/golden/dry_members.npz)"}
     return res
+
+
+def golden_stiff_chain(eng, opts):
+    """The network kernel and the benchmarked solver settings (second pair included) against tables the UNMODIFIED reference made
+    with odeint at rtol=atol=1e-12 for a 12-reach chain whose outlet relaxes ~300 times a day (tests/golden/stiff_chain12_2004.npz):
+    worst relative error over the 9 reach columns of all 12 reaches x 366 days."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    from simplyp_amd import marshal
+    name = 'stiff_chain12_2004'
+    if not os.path.exists(os.path.join(helpers.GOLDEN, name + '.npz')):
+        return None
+    m = helpers.marshal_scenario(name, E=64)
+    for k in ('integrator', 'substeps', 'rtol', 'atol', 'max_steps', 'project_vr', 'stiff_pair'):
+        setattr(m['opts'], k, getattr(opts, k))
+    out, status, st = eng.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])
+    got = out[..., 0].cpu().numpy()
+    gold = helpers.golden_tables(name, 'tight')['R']
+    per_reach = [max(helpers.max_rel_err(got[marshal.OUT_COLUMNS.index(c), :, j], gold[sc][c].values, floor=1e-300) for c in GOLDEN_REACH_COLS)
+                 for j, sc in enumerate(m['scs'])]
+    return {"max_rel_err": float(max(per_reach)), "per_reach": [float(x) for x in per_reach], "bar": 1e-6, "second_pair_used": int(st.get('stiff_pair', 0)),
+            "rhs_evals_per_catchment_day": st['rhs_evals'] / float(64 * len(m['scs']) * got.shape[1]),
+            "against": "the unmodified reference, odeint rtol=atol=1e-12, 12-reach chain with an outlet flow of ~300 mm/d (tests/golden/stiff_chain12_2004.npz)"}
 
 
 def reference_python_rate():

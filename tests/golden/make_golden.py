@@ -205,6 +205,29 @@ def scenarios(long_run):
     s['p']['k_M'] = 1.7
     out['chain4_val_2004'] = s
 
+    # 5. (round 4) a 12-reach chain that ends in a short reach with a small catchment of its own: the flow of 500 km2 through a 2 km
+    #    reach of a 5 km2 sub-catchment relaxes at ~300 per day -- the stiff end of a reach network, where an explicit pair's steps
+    #    are bound by stability and the engine's second pair (opts.stiff_pair) takes over.  Newly-converted land on two reaches.
+    s = base('2004-01-01', '2004-12-31')
+    s['dyn'] = dict(Dynamic_EPC0='y', Dynamic_erodibility='y')
+    areas = [50., 45., 50., 40., 50., 48., 50., 42., 50., 46., 20., 5.]
+    lengths = [8000., 9000., 7000., 10000., 6000., 8500., 7500., 9500., 6500., 8000., 4000., 2000.]
+    fracs = [(0.25, 0.25, 0.5), (0.125, 0.375, 0.5), (0.2, 0.3, 0.5), (0.5, 0.25, 0.25), (0.125, 0.125, 0.75), (0.25, 0.5, 0.25),
+             (0.375, 0.125, 0.5), (0.2, 0.3, 0.5), (0.25, 0.25, 0.5), (0.125, 0.25, 0.625), (0.5, 0.125, 0.375), (0.25, 0.25, 0.5)]
+    cols = []
+    for i in range(12):
+        c = dict(A_catch=areas[i], L_reach=lengths[i], f_Ar=fracs[i][0], f_IG=fracs[i][1], f_S=fracs[i][2],
+                 S_reach=[0.8, 1.2, 0.6, 1.5, 0.9, 1.1, 0.7, 1.3, 1.0, 0.5, 1.4, 2.0][i], S_Ar=3. + (i % 4), S_IG=2. + (i % 3), S_SN=8. + (i % 5),
+                 TDPeff=[0.1, np.nan, 0.0, 0.3, 0.05, 0.0, 0.2, np.nan, 0.1, 0.0, 0.4, 0.02][i])
+        if i in (3, 7):
+            c['f_NC_Ar'] = 0.2
+        cols.append(c)
+    s['p'], s['p_SC'], s['p_struc'] = make_multi_reach(s['p'], s['p_SC'], s['p_struc'], cols,
+                                                       upstream=[np.nan] + list(range(1, 12)), final_flux=[0] * 11 + [1])
+    s['p_SU'] = s['p_SU'].copy(); s['p_SU']['n_SC'] = 12
+    s['p']['SC_Qr0'] = 12.0
+    out['stiff_chain12_2004'] = s
+
     if long_run:
         s = base('1981-01-01', '2010-12-31')
         s['dyn'] = dict(Dynamic_EPC0='y', Dynamic_erodibility='y')

@@ -24,7 +24,7 @@ from simplyp_amd import abi, engine, ensemble, marshal, synthetic
 
 pytestmark = pytest.mark.gpu
 
-SCENARIOS = ['tarland_2004_static', 'tarland_2004_dynamic', 'confluence3_nc_2004', 'chain4_val_2004']
+SCENARIOS = ['tarland_2004_static', 'tarland_2004_dynamic', 'confluence3_nc_2004', 'chain4_val_2004', 'stiff_chain12_2004']
 REACH_COLS = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day',
               'PPr_EndOfDay', 'PP_kg/day']
 FLOOR = 1e-12      # columns that are identically 0 (e.g. NC columns without NC land) compare absolutely
