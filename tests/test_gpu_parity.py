@@ -65,6 +65,8 @@ def test_native_library_is_the_one_running(engine0):
     (dict(integrator='cashkarp_aug', rtol=1e-6, atol=1e-9), 1e-5),
     (dict(integrator='cashkarp', rtol=1e-6, atol=1e-9, project_vr=0), 1e-5)])
 def test_kernel_matches_oracle(engine0, oracle_lib, name, solver, tol):
+    if name == 'stiff_chain12_2004' and solver and solver.get('integrator') == 'rk4':
+        solver = dict(solver, substeps=384)      # the outlet relaxes ~300-700 times a day: classical RK4 is stable for h x rate < 2.78
     m = helpers.marshal_scenario(name, E=3, solver=solver)
     got, status, stats = gpu_run(engine0, m)
     ref, rstatus, rstats = cpu_run(oracle_lib, m)
