@@ -103,19 +103,12 @@ def c3_problem(n_members, st_dt='1981-01-01', end_dt='2010-12-31', seed=C3_SEED,
 C4_SEED = 20240602
 
 
-def c4_problem(n_members, n_reaches=256, n_days=18262, seed=C4_SEED, solver=None, out_mask=marshal.MASK_REACH5,
-               out_reaches='last'):
-    """BASELINE config C4: a synthetic linear chain of `n_reaches` sub-catchments (reach i drains reach i-1),
-    4 land-use classes active (IG erodibility, newly-converted arable land on every 4th reach), Tarland forcing
-    tiled to `n_days` (1981-2010 then again from 1981), members drawn from the C3 distribution.
-
-    Per-reach parameters (SURVEY.md section 8d): A_catch log-uniform 5-50 km2, L_reach 2-15 km, slopes 1-12
-    degrees, land-use fractions Dirichlet(2,3,5) rounded to multiples of 1/1024 so that f_Ar + f_IG + f_S == 1
-    exactly in floating point, f_NC_Ar = 0.1 on every 4th reach."""
-    from . import abi
+def c4_inputs(n_reaches=256, seed=C4_SEED, st_dt='1981-01-01', end_dt='2010-12-31'):
+    """The reference-shaped inputs (the 7 arguments of run_simply_p) of BASELINE config C4's synthetic reach chain: the Tarland
+    workbook with `n_reaches` sub-catchments in a line (reach i drains reach i - 1), both dynamic options on.  Per-reach
+    parameters are drawn reach by reach, so a shorter chain is the upper end of the 256-reach one."""
     import pandas as pd
-    met_df, p_struc, p_SU, p_LU, p_SC, p, dyn = tarland_inputs('1981-01-01', '2010-12-31', dynamic_epc0='y',
-                                                               dynamic_erod='y')
+    met_df, p_struc, p_SU, p_LU, p_SC, p, dyn = tarland_inputs(st_dt, end_dt, dynamic_epc0='y', dynamic_erod='y')
     rng = np.random.default_rng(seed)
     S = int(n_reaches)
     frac = np.round(rng.dirichlet([2.0, 3.0, 5.0], S) * 1024.0)
@@ -139,8 +132,26 @@ def c4_problem(n_members, n_reaches=256, n_days=18262, seed=C4_SEED, solver=None
     p = p.copy()
     p['SC_list'] = np.arange(1, S + 1)
     p['SC_Qr0'] = float(S)
+    p_SU = p_SU.copy()
+    p_SU['n_SC'] = S
     p_struc = pd.DataFrame({'Upstream_SCs': pd.Series([np.nan] + list(range(1, S)), index=range(1, S + 1), dtype=object),
                             'In_final_flux?': pd.Series([0] * (S - 1) + [1], index=range(1, S + 1))})
+    p_struc.index.name = 'Reach'
+    return met_df, p_struc, p_SU, p_LU, p_SC, p, dyn
+
+
+def c4_problem(n_members, n_reaches=256, n_days=18262, seed=C4_SEED, solver=None, out_mask=marshal.MASK_REACH5,
+               out_reaches='last'):
+    """BASELINE config C4: a synthetic linear chain of `n_reaches` sub-catchments (reach i drains reach i-1),
+    4 land-use classes active (IG erodibility, newly-converted arable land on every 4th reach), Tarland forcing
+    tiled to `n_days` (1981-2010 then again from 1981), members drawn from the C3 distribution.
+
+    Per-reach parameters (SURVEY.md section 8d): A_catch log-uniform 5-50 km2, L_reach 2-15 km, slopes 1-12
+    degrees, land-use fractions Dirichlet(2,3,5) rounded to multiples of 1/1024 so that f_Ar + f_IG + f_S == 1
+    exactly in floating point, f_NC_Ar = 0.1 on every 4th reach."""
+    from . import abi
+    met_df, p_struc, p_SU, p_LU, p_SC, p, dyn = c4_inputs(n_reaches, seed)
+    S = int(n_reaches)
     marshal.prologue(p_SU, p_LU, p_SC, p)
     up_ptr, up_idx, _ = marshal.topology(p_struc, p)
     over = monte_carlo_overrides(p, p_LU, n_members, seed)

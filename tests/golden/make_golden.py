@@ -15,7 +15,7 @@ How the reference is driven:
     either as shipped (rtol=0.01, default atol, mxstep=5000) or at rtol=atol=1e-12
     ("tight": the converged solution of the reference's own equations = the parity oracle).
 
-Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout|dry]
+Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout|dry|dry-check|c4mc]
 """
 
 import argparse
@@ -512,6 +512,51 @@ def dry_convergence_check(n_proc):
                   % (DRY_MEMBERS[k][2], t[0], t[1], ' '.join('%s %.1e' % (c, v) for c, v in zip(REACH_COLS, d))), flush=True)
 
 
+# Members of BASELINE config C4's own distribution on the upper 16 reaches of its synthetic chain (simplyp_amd.synthetic.c4_inputs /
+# c4_problem: the same reach geometry, the same parameter draws), 1981, through the unmodified reference at rtol=atol=1e-12: pins the
+# network kernel -- routing, newly-converted land on every 4th reach, both dynamic options, the second pair on the reaches further
+# down -- to the reference across the parameter distribution, not only at the workbook's values.
+C4MC_REACHES, C4MC_MEMBERS, C4MC_KEEP = 16, 4, (1, 6, 11, 16)
+
+
+def _c4_member_worker(member):
+    from simplyp_amd import synthetic, marshal
+    mods = load_reference()
+    switch = OdeintSwitch()
+    mods['model'].odeint = switch
+    p_SU, p, p_LU, _, _, met = tarland_inputs('1981-01-01', '1981-12-31')
+    _, p_struc, p_SU4, _, p_SC, p4, _ = synthetic.c4_inputs(C4MC_REACHES, synthetic.C4_SEED, '1981-01-01', '1981-12-31')
+    p = p.copy()
+    p['SC_list'], p['SC_Qr0'] = p4['SC_list'], p4['SC_Qr0']
+    p_SU = p_SU.copy()
+    p_SU['n_SC'] = C4MC_REACHES
+    over = synthetic.monte_carlo_overrides(p, p_LU, C4MC_MEMBERS, seed=synthetic.C4_SEED)
+    sc = dict(p_SU=p_SU, p=p, p_LU=p_LU.copy(), p_SC=p_SC, p_struc=p_struc, met=met, dyn=dict(Dynamic_EPC0='y', Dynamic_erodibility='y'))
+    for name in over:
+        src = dict(marshal.PM_SPEC)[name]
+        if src[0] == 'p':
+            sc['p'][src[1]] = float(over[name][member])
+        else:
+            sc['p_LU'].loc[src[1], src[2]] = float(over[name][member])
+    r = run_reference(mods, switch, sc, 1e-12)
+    print('C4 member %d: wall %.1f s  nfe/day %.1f' % (member, r['wall'], r['nfe_per_day']), flush=True)
+    return member, {sc_id: r['df_R'][sc_id][REACH_COLS].to_numpy(dtype=float) for sc_id in C4MC_KEEP}, {k: float(over[k][member]) for k in sorted(over)}
+
+
+def c4_members_fixture(n_proc):
+    import multiprocessing as mp
+    with mp.get_context('fork').Pool(min(n_proc, C4MC_MEMBERS)) as pool:
+        res = pool.map(_c4_member_worker, range(C4MC_MEMBERS), chunksize=1)
+    arrays = {'n_reaches': np.array(C4MC_REACHES), 'n_members': np.array(C4MC_MEMBERS), 'reaches': np.array(C4MC_KEEP),
+              'columns': np.array(REACH_COLS), 'names': np.array(sorted(res[0][2])),
+              'values': np.array([[ov[k] for (_, _, ov) in res] for k in sorted(res[0][2])])}
+    for m, tabs, _ in res:
+        for sc_id, R in tabs.items():
+            arrays['R/%d/%d' % (m, sc_id)] = R
+    np.savez_compressed(os.path.join(HERE, 'c4_members.npz'), **arrays)
+    print('c4_members.npz written')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--long', action='store_true', help='also run the 1981-2010 scenario (minutes)')
@@ -527,6 +572,9 @@ def main():
         return
     if args.only == 'dry':
         dry_fixture(args.procs)
+        return
+    if args.only == 'c4mc':
+        c4_members_fixture(args.procs)
         return
     if args.only == 'dry-check':
         dry_convergence_check(args.procs)

@@ -202,3 +202,27 @@ def dry_worst_per_member(got, tables, columns):
     cols = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
     return [max(max_rel_err(got[columns.index(c), lo:hi, 0, k], tab[:, j], floor=1e-300) for j, c in enumerate(cols))
             for k, (lo, hi, tab) in enumerate(tables)]
+
+
+def c4_members_problem(solver=None):
+    """Arrays + opts for tests/golden/c4_members.npz -- 4 members of BASELINE config C4's own distribution on the upper 16 reaches of
+    its chain, 1981, run through the unmodified reference at rtol=atol=1e-12 (tests/golden/make_golden.py --only c4mc) -- and the
+    reference tables: (problem dict with all 25 columns of the kept reaches, {(member, position among the kept reaches): table[366, 9]})."""
+    from simplyp_amd import synthetic, marshal
+    z = np.load(os.path.join(GOLDEN, 'c4_members.npz'), allow_pickle=False)
+    S, E = int(z['n_reaches']), int(z['n_members'])
+    keep = [int(r) for r in z['reaches']]
+    pr = synthetic.c4_problem(E, n_reaches=S, n_days=365, solver=solver, out_mask=marshal.MASK_ALL, out_reaches=[r - 1 for r in keep])
+    for k, nm in enumerate(str(n) for n in z['names']):                 # the generator still draws what the fixture recorded
+        np.testing.assert_array_equal(pr['member_params'][marshal.PM_NAMES.index(nm)], z['values'][k])
+    tables = {(m, j): z['R/%d/%d' % (m, r)] for m in range(E) for j, r in enumerate(keep)}
+    assert all(t.shape == (365, 9) for t in tables.values())
+    return pr, tables
+
+
+def c4_members_worst(got, tables):
+    """max relative error over the 9 reach columns, per (member, kept reach); got [25, 365, n_kept, E]"""
+    from simplyp_amd import marshal
+    cols = ['Vr', 'Qr_EndOfDay', 'Qr', 'Msus_EndOfDay', 'Msus_kg/day', 'TDPr_EndOfDay', 'TDP_kg/day', 'PPr_EndOfDay', 'PP_kg/day']
+    return {key: max(max_rel_err(got[marshal.OUT_COLUMNS.index(c), :, key[1], key[0]], tab[:, j], floor=1e-300) for j, c in enumerate(cols))
+            for key, tab in tables.items()}

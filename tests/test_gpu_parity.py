@@ -876,3 +876,16 @@ def test_second_pair_on_a_stiff_reach_chain(engine0, oracle_lib, lanes):
     if lanes == 4:        # bit-identical to the one-lane kernel, second pair included
         one, s_one = run(1, n_lanes=1)
         assert np.array_equal(one, on, equal_nan=True) and s_one['rhs_evals'] == s_on['rhs_evals'] and s_one['rejected'] == s_on['rejected']
+
+
+@pytest.mark.parametrize('lanes', [1, 4])
+def test_default_solver_on_members_of_the_c4_distribution_against_the_reference(engine0, lanes):
+    """tests/golden/c4_members.npz (4 members of config C4's own distribution on the upper 16 reaches of its chain, made by the
+    unmodified reference at rtol=atol=1e-12) through the KERNEL, default solver with the second pair, one and four lanes per member:
+    north_star's bar on all 9 reach columns."""
+    pr, tables = helpers.c4_members_problem(solver=dict(lanes_per_member=lanes))
+    out, status, stats = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], pr['opts'],
+                                     out_reaches=pr['out_reaches'])
+    assert int(status.max()) == 0 and stats['lanes_per_member'] == lanes and stats['stiff_pair'] == 1
+    worst = helpers.c4_members_worst(out.cpu().numpy(), tables)
+    assert max(worst.values()) < 1e-6, worst

@@ -325,3 +325,18 @@ def test_oracle_second_pair_on_a_stiff_reach_chain(oracle_lib):
         outs[sp] = oracle_lib.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'])[0]
     assert np.array_equal(outs[0], outs[-1])
     assert helpers.max_rel_err(outs[1], outs[-1], floor=1e-300) < 1e-6
+
+
+def test_oracle_default_solver_on_members_of_the_c4_distribution_against_the_reference(oracle_lib):
+    """tests/golden/c4_members.npz: 4 members of config C4's own parameter distribution on the upper 16 reaches of its chain (routing,
+    newly-converted land on every 4th reach, both dynamic options), one year, through the unmodified reference at rtol=atol=1e-12.
+    Default solver (second pair on: a network) and Cash-Karp alone: north_star's bar on all 9 reach columns of the kept reaches."""
+    pr, tables = helpers.c4_members_problem()
+    for stiff in (0, -1):
+        pr['opts'].stiff_pair = stiff
+        out, status, _ = oracle_lib.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], pr['opts'],
+                                        out_reaches=pr['out_reaches'], n_threads=4)
+        assert status.max() == 0
+        worst = helpers.c4_members_worst(out, tables)
+        assert max(worst.values()) < 1e-6, (stiff, worst)
+    pr['opts'].stiff_pair = 0
