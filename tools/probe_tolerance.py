@@ -23,10 +23,10 @@ print('seed', SEED, ('snow, T_air %+g' % TSHIFT) if SNOW else '', 'wide x/%g' % 
 
 def run(solver):
     pr = synthetic.c3_problem(E, seed=SEED, solver=dict(solver, balance=0, time_chunk_days=-1))
-    if WIDE != 1:      # a wider parameter distribution than BASELINE C3's: soil, groundwater and reach time scales
-        from simplyp_amd import marshal
+    if WIDE != 1:      # a wider parameter distribution than BASELINE C3's: soil, groundwater and reach time scales (synthetic.widen_overrides:
+        from simplyp_amd import marshal      # the same draw the dry-reach fixture of tests/golden/make_golden.py uses)
         rng = np.random.default_rng(SEED + 2000)
-        for name in ('T_s_A', 'T_s_S', 'T_g', 'a_Q', 'E_M', 'f_quick'):
+        for name in synthetic.WIDE_NAMES:
             pr['member_params'][marshal.PM_NAMES.index(name)] *= np.exp(rng.uniform(-np.log(WIDE), np.log(WIDE), E))
     if PSCALE != 1 and not SNOW:
         pr['forcing'] = pr['forcing'].copy()
