@@ -745,6 +745,315 @@ static void cashkarp_aug_f32_day(double* y, const ode_params* p, double T_, doub
     y[3] = Kv * pow(y[4], 1.0 - p->b_Q);
 }
 
+
+/* ------------------------------------------------------------------------------------- */
+/*
+ * ORACLE_INTEG_SPLIT_AUG -- a PROBE of this file only (tools/probe_split.py; not in include/simplyp.h, no kernel): scheme 2 with the
+ * slow stores split off, the numerical design behind DESIGN.md section 7 "Next for C4".
+ *
+ * The two soil boxes and the groundwater store do not depend on the reach's own states (model.py:105-124: forcing, member parameters
+ * and the land-use shares only), and they are slow: a handful of steps a day resolve them where the reach -- whose flow equation
+ * relaxes in 1/400 to 1/15 of a day and restarts a transient at every midnight -- takes ~30.  A day is integrated in two passes per
+ * segment:
+ *   slow pass:  w = VsA VsS Vg EA ES by Cash-Karp under the knee-aware controller (all three gates live here), tolerances
+ *               g_split_slow_tol x the run's; each accepted step leaves one interval of a record: its length and the Hermite
+ *               polynomials (cubic, or quintic with the second derivatives), in the time since the interval's start, of the two
+ *               combinations the reach sees --
+ *                   L = (1 - beta)(f_A QsA + f_S QsS) + Qg      (land-phase inflow, :127-129)
+ *                   M = tA QsA + tS QsS + tg Qg                 (its TDP load, :154-163)
+ *               with their exact time derivatives at the knots (chain rule through the gates);
+ *   reach pass: z = Qr Msus TDPr PPr pb pk (+ the four daily integrals) over the record's intervals, one after the other, a step
+ *               never crossing an interval's end -- same pairs, same controller as scheme 2 for what is left: no gate, hence no knee rule.
+ * A segment holds at most g_split_ni intervals (a kernel would keep the record in LDS).
+ * What it showed (profiles/r04_c4/split_prototype.log): the split itself is sound (2.5e-10 from the converged scheme at rtol 1e-11),
+ * the reach pass needs 6 instead of 11 states and a right-hand side a third the size -- but the record, not the slow integration,
+ * sets the slow pass's step: a gate's zone is 1 % of its threshold wide and the flow through it a quartic of the store, so a cubic
+ * record needs ~14-20 knots a day to hold the references' fixtures at 2e-7, and a quintic one (exact on the quartic) is thrown by the
+ * jump of L'' at a gate's upper knee unless it has as many.
+ */
+#define ORACLE_INTEG_SPLIT_AUG 14
+#define SPLIT_NI_MAX 64
+typedef struct { int n; double hk[SPLIT_NI_MAX], L[SPLIT_NI_MAX][6], M[SPLIT_NI_MAX][6]; } split_record;
+static double g_split_slow_tol = 1.0e-4;
+static int g_split_ni = 6, g_split_carry = 1, g_split_cut_keeps = 1;
+static double g_split_h0 = 0.05;
+static int g_split_order = 5;
+void simplyp_oracle_split_order(int o) { g_split_order = o; }
+static uint64_t g_split_slow_attempts = 0, g_split_reach_attempts = 0, g_split_segments = 0, g_split_slow_max = 0;
+void simplyp_oracle_split_config(double slow_tol, int ni, int carry, int cut_keeps, double h0)
+{
+    g_split_slow_tol = slow_tol; g_split_ni = ni; g_split_carry = carry; g_split_cut_keeps = cut_keeps; g_split_h0 = h0;
+    g_split_slow_attempts = g_split_reach_attempts = g_split_segments = g_split_slow_max = 0;
+}
+void simplyp_oracle_split_counts(uint64_t* c4) { c4[0] = g_split_slow_attempts; c4[1] = g_split_reach_attempts; c4[2] = g_split_segments; c4[3] = g_split_slow_max; }
+
+typedef struct {            /* the day's constants in the kernel's grouping (DayConst) */
+    double c0, aE, mu, fc, inv_d, invTsA, invTsS, invTg, Qgmin, inv_dg, beta, fA, fS, omb, tA, tS, tg, dgate, dgq;
+} slow_const;
+
+static double gate_d(double u, double inv_d, double* dg, double* d2g)      /* f_x as one clamped cubic; its first and second derivative in u */
+{
+    double sc = u * inv_d;
+    const int inside = sc > 0.0 && sc < 1.0;
+    sc = fmin(fmax(sc, 0.0), 1.0);
+    *dg = 6.0 * sc * (1.0 - sc) * inv_d;
+    *d2g = inside ? (6.0 - 12.0 * sc) * inv_d * inv_d : 0.0;
+    return sc * sc * (3.0 - 2.0 * sc);
+}
+
+/* dw/dt of the slow stores; lm = L, M and (dlm) their first and second time derivatives at this point: dlm = L', M', L'', M'' */
+static void slow_rhs(const double* w, const slow_const* c, double* dw, double* lm, double* dlm)
+{
+    double dgA, dgS, dgG, hgA, hgS, hgG;
+    const double uA = w[0] - c->fc, uS = w[1] - c->fc;
+    const double gA = gate_d(uA, c->inv_d, &dgA, &hgA), gS = gate_d(uS, c->inv_d, &dgS, &hgS);
+    const double QsA = uA * c->invTsA * gA, QsS = uS * c->invTsS * gS;
+    dw[0] = c->c0 + c->aE * (w[3] - 1.0) - QsA;
+    dw[1] = c->c0 + c->aE * (w[4] - 1.0) - QsS;
+    const double Qsum = c->fA * QsA + c->fS * QsS;
+    const double ug = w[2] * c->invTg - c->Qgmin;
+    const double gG = gate_d(ug, c->inv_dg, &dgG, &hgG);
+    const double Qg = c->Qgmin + gG * ug;
+    dw[2] = c->beta * Qsum - Qg;
+    dw[3] = -c->mu * w[3] * dw[0];
+    dw[4] = -c->mu * w[4] * dw[1];
+    lm[0] = c->omb * Qsum + Qg;
+    lm[1] = c->tA * QsA + c->tS * QsS + c->tg * Qg;
+    if (dlm) {
+        const double qA1 = (gA + uA * dgA) * c->invTsA, qS1 = (gS + uS * dgS) * c->invTsS, qG1 = gG + ug * dgG;       /* dQ/du */
+        const double qA2 = (2.0 * dgA + uA * hgA) * c->invTsA, qS2 = (2.0 * dgS + uS * hgS) * c->invTsS, qG2 = 2.0 * dgG + ug * hgG;
+        const double dQsA = qA1 * dw[0], dQsS = qS1 * dw[1];
+        const double ugd = c->invTg * dw[2];
+        const double dQg = qG1 * ugd;
+        const double uA2 = c->aE * dw[3] - dQsA, uS2 = c->aE * dw[4] - dQsS;           /* d2 Vs / dt2 */
+        const double ug2 = c->invTg * (c->beta * (c->fA * dQsA + c->fS * dQsS) - dQg);
+        const double d2QsA = qA2 * dw[0] * dw[0] + qA1 * uA2, d2QsS = qS2 * dw[1] * dw[1] + qS1 * uS2;
+        const double d2Qg = qG2 * ugd * ugd + qG1 * ug2;
+        dlm[0] = c->omb * (c->fA * dQsA + c->fS * dQsS) + dQg;
+        dlm[1] = c->tA * dQsA + c->tS * dQsS + c->tg * dQg;
+        dlm[2] = c->omb * (c->fA * d2QsA + c->fS * d2QsS) + d2Qg;
+        dlm[3] = c->tA * d2QsA + c->tS * d2QsS + c->tg * d2Qg;
+    }
+}
+
+/* Hermite interpolant on [0, hk] in powers of the time since the interval's start: cubic from values and slopes (order 3), quintic
+ * with the second derivatives too (order 5; c[4], c[5] are 0 for the cubic) */
+static void hermite(int order, double f0, double d0, double s0, double f1, double d1, double s1, double hk, double* c)
+{
+    const double ih = 1.0 / hk, sl = (f1 - f0) * ih;
+    c[0] = f0; c[1] = d0;
+    if (order == 3) {
+        c[2] = (3.0 * sl - 2.0 * d0 - d1) * ih;
+        c[3] = ((d0 + d1) - 2.0 * sl) * ih * ih;
+        c[4] = c[5] = 0.0;
+    } else {
+        const double a = s0 * hk, b = s1 * hk;      /* second derivatives x hk: same units as the slopes */
+        c[2] = 0.5 * s0;
+        c[3] = 0.5 * (20.0 * sl - 8.0 * d1 - 12.0 * d0 - (3.0 * a - b)) * ih * ih;
+        c[4] = 0.5 * (-30.0 * sl + 14.0 * d1 + 16.0 * d0 + (3.0 * a - 2.0 * b)) * ih * ih * ih;
+        c[5] = 0.5 * (12.0 * sl - 6.0 * (d1 + d0) - (a - b)) * ih * ih * ih * ih;
+    }
+}
+
+typedef struct { double qin, cQ, bQ, kM, Esum, MsusUS, tconst, cPP, PPrUS, invKv; } reach_const;
+#define NRZ 10     /* Qr Msus TDPr PPr pb pk | Qr_av Msus_out TDP_out PP_out */
+static void reach_rhs(double tau, const double* z, const reach_const* c, const double* cl, const double* cm, double* dz)
+{
+    const double L = cl[0] + tau * (cl[1] + tau * (cl[2] + tau * (cl[3] + tau * (cl[4] + tau * cl[5]))));
+    const double M = cm[0] + tau * (cm[1] + tau * (cm[2] + tau * (cm[3] + tau * (cm[4] + tau * cm[5]))));
+    const double Qr = z[0], pb = z[4], pk = z[5];
+    const double inflow = (L + c->qin) - Qr;
+    const double dQr = inflow * (c->cQ * pb);
+    const double kap = pb * c->invKv;
+    const double oM = z[1] * kap, oT = z[2] * kap, oP = z[3] * kap;
+    dz[0] = dQr;
+    dz[1] = c->Esum * pk + c->MsusUS - oM;
+    dz[2] = (M + c->tconst) - oT;
+    dz[3] = c->cPP * pk + c->PPrUS - oP;
+    const double r = dQr / Qr;
+    dz[4] = c->bQ * pb * r; dz[5] = c->kM * pk * r;
+    dz[6] = Qr; dz[7] = oM; dz[8] = oT; dz[9] = oP;
+}
+
+static void split_day(double* y, const ode_params* p, double T, double rtol, double atol, int max_steps,
+                      double* h_carry, double* h_slow, integ_stats* st, int use_stiff)
+{
+    static const double CN[6] = {0.0, 1.0 / 5, 3.0 / 10, 3.0 / 5, 1.0, 7.0 / 8};       /* Cash-Karp's nodes */
+    double cS[6]; { cS[0] = 0.0; for (int s = 1; s < 6; ++s) { double a = 0; for (int j = 0; j < s; ++j) a += TAB_STIFF.A[s][j]; cS[s] = a; } }
+    slow_const sc; reach_const rc;
+    if (!state_finite(y)) { y[5] = y[7] = y[9] = y[11] = NAN; st->poisoned = 1; return; }
+    {
+        const double wA = p->f_A * (1 - p->f_NC_A), wNC = p->f_A * p->f_NC_A + p->f_S * p->f_NC_S;
+        sc.c0 = p->P * (1 - p->f_quick); sc.aE = p->alpha * p->E; sc.mu = p->mu; sc.fc = p->fc; sc.inv_d = 1.0 / (0.01 * p->fc);
+        sc.invTsA = 1.0 / p->T_s_A; sc.invTsS = 1.0 / p->T_s_S; sc.invTg = 1.0 / p->T_g; sc.Qgmin = p->Qg_min;
+        sc.inv_dg = (p->Qg_min * 0.01 > 0.0) ? 1.0 / (p->Qg_min * 0.01) : 1.0e300;
+        sc.beta = p->beta; sc.fA = p->f_A; sc.fS = p->f_S; sc.omb = 1.0 - p->beta;
+        const double tNC = sc.omb * wNC * p->conc_TDPs_NC;
+        sc.tA = sc.omb * wA * p->conc_TDPs_A + (p->NC_type == 1 ? tNC : 0.0);
+        sc.tS = (p->NC_type == 1 ? 0.0 : tNC);
+        sc.tg = p->TDPg * p->A_catch; sc.dgate = 0.01 * p->fc; sc.dgq = 0.01 * p->Qg_min;
+        rc.qin = p->Qq_i + p->Qr_US_i;
+        rc.cQ = p->a_Q * (8.64 * 10000) / ((1 - p->b_Q) * (p->L_reach)); rc.bQ = p->b_Q; rc.kM = p->k_M;
+        rc.Esum = p->f_Ar * p->Esus_A + p->f_IG * p->Esus_IG + p->f_S * p->Esus_S; rc.MsusUS = p->Msus_US_i;
+        rc.tconst = p->Qq_i * (wA * p->conc_TDPs_A + wNC * p->conc_TDPs_NC) + p->TDPeff + p->TDPr_US_i;
+        const double pA = (p->PlabA_i + p->P_inactive) / p->Msoil, pN = (p->PlabNC_i + p->P_inactive) / p->Msoil, p0 = p->P_inactive / p->Msoil;
+        rc.cPP = p->E_PP * (p->f_Ar * p->Esus_A * ((1 - p->f_NC_Ar) * pA + p->f_NC_Ar * pN)
+                            + p->f_IG * p->Esus_IG * ((1 - p->f_NC_IG) * pA + p->f_NC_IG * pN)
+                            + p->f_S * p->Esus_S * ((1 - p->f_NC_S) * p0 + p->f_NC_S * pN));
+        rc.PPrUS = p->PPr_US_i;
+        rc.invKv = (p->a_Q * 8.64 * 10000) / p->L_reach;
+    }
+    const double rtol_s = rtol * g_split_slow_tol, atol_s = atol * g_split_slow_tol;
+    double w[5] = {y[0], y[1], y[2], exp(-p->mu * y[0]), exp(-p->mu * y[1])};
+    double z[NRZ] = {y[4], y[6], y[8], y[10], pow(y[4], p->b_Q), pow(y[4], p->k_M), 0.0, 0.0, 0.0, 0.0};
+    double ts = 0.0, hs = g_split_carry ? *h_slow : g_split_h0 * T;
+    double h = *h_carry * AUG_DAY_START;
+    int slow_attempts = 0, attempts = 0;
+    if (!(hs > 0.0) || hs > T) hs = T;
+    if (!(h > 0.0) || h > T) h = T;
+    if (use_stiff && h * rc.cQ * z[4] > SIMPLYP_STIFF_Z_START) h = SIMPLYP_STIFF_Z_START / (rc.cQ * z[4]);
+    split_record rec;
+    while (ts < T) {
+        /* ---- slow pass: up to g_split_ni accepted steps ---- */
+        double k[6][5], wt[5], wn[5], F[2], dF[4], Fn[2], dFn[4], kn[5], lms[2];
+        const erk_tableau* ck = &TAB_CASHKARP;
+        rec.n = 0; ++g_split_segments;
+        slow_rhs(w, &sc, k[0], F, dF);
+        while (ts < T && rec.n < g_split_ni) {
+            double rem = T - ts, hh = hs;
+            if (rem <= 1.1 * hs) hh = rem; else if (rem < 2.0 * hs) hh = 0.5 * rem;
+            const int last_chance = (slow_attempts + 1 >= max_steps);
+            if (last_chance) hh = rem;
+            int targeted = 0, kink = 0, kink_gw = 0;
+            {
+                double hsl = 1.0e300, hg = 1.0e300, ugd = 0.0;
+                const double tlo = AUG_KNEE_LO * hh;
+                for (int i = 0; i < 3; ++i) {
+                    const double g = (i < 2) ? w[i] - sc.fc : w[2] * sc.invTg - sc.Qgmin;
+                    const double sl = (i < 2) ? k[0][i] : k[0][2] * sc.invTg;
+                    const double gd = (i < 2) ? sc.dgate : sc.dgq;
+                    const double gdg = gd - g;
+                    const double t0 = (0.0 - g) / sl, t1 = gdg / sl;
+                    double tn = 1.0e300;
+                    if (t0 > tlo && t0 < tn) tn = t0;
+                    if (t1 > tlo && t1 < tn) tn = t1;
+                    if (i < 2) { if (tn < hsl) hsl = tn; } else { hg = tn; ugd = gdg; }
+                }
+                const double hk = fmin(hsl, hg);
+                if (!last_chance && hk * AUG_KNEE_OVER < AUG_KNEE_HI * hh) { hh = hk * AUG_KNEE_OVER; targeted = 1; }
+                const double look = AUG_KINK_REACH * hh;
+                kink = hsl < look;
+                kink_gw = (hg < look) | (kink & (ugd > 0.0));
+            }
+            for (int s = 1; s < 6; ++s) {
+                for (int i = 0; i < 5; ++i) {
+                    double acc = 0.0;
+                    for (int j = 0; j < s; ++j) acc += ck->A[s][j] * k[j][i];
+                    wt[i] = w[i] + hh * acc;
+                }
+                slow_rhs(wt, &sc, k[s], lms, NULL);
+            }
+            double err = 0.0; int bad = 0;
+            for (int i = 0; i < 5; ++i) {
+                double inc = 0.0, ee = 0.0;
+                for (int s = 0; s < 6; ++s) { inc += ck->B[s] * k[s][i]; ee += ck->E[s] * k[s][i]; }
+                wn[i] = w[i] + hh * inc;
+                if (!(fabs(wn[i]) < 1.0e300)) bad = 1;
+                if (i >= 3) continue;
+                const double ref = (i < 2) ? w[i] - sc.fc : w[i], pred = ref + hh * k[0][i];
+                double wgt = fmax(fabs(ref), fabs(pred));
+                if (i < 2) wgt = fmax(wgt, sc.dgate);
+                const double r = fabs(hh * ee) / (atol_s + rtol_s * wgt);
+                if (r > err) err = r;
+            }
+            if (kink_gw) err *= targeted ? AUG_KNEE_GW : AUG_KINK_GW;
+            else if (kink && !targeted) err *= AUG_KINK_SOIL;
+            if (!(err < 1.0e300)) bad = 1;
+            ++slow_attempts; ++g_split_slow_attempts; st->rhs += 6;
+            if (last_chance) st->capped = 1;
+            if (bad && (last_chance || hh <= 1.0e-9 * T)) { for (int i = 0; i < NY; ++i) y[i] = NAN; st->poisoned = 1; return; }
+            else if (!bad && (err <= 1.0 || last_chance)) {
+                slow_rhs(wn, &sc, kn, Fn, dFn);
+                const int n = rec.n;
+                rec.hk[n] = hh;
+                hermite(g_split_order, F[0], dF[0], dF[2], Fn[0], dFn[0], dFn[2], hh, rec.L[n]);
+                hermite(g_split_order, F[1], dF[1], dF[3], Fn[1], dFn[1], dFn[3], hh, rec.M[n]);
+                rec.n = n + 1;
+                memcpy(w, wn, sizeof(wn)); memcpy(k[0], kn, sizeof(kn)); memcpy(F, Fn, sizeof(Fn)); memcpy(dF, dFn, sizeof(dFn));
+                ts = (hh == rem) ? T : ts + hh;
+                st->steps++;
+            } else st->rejected++;
+            double fac;
+            if (bad) fac = SIMPLYP_CTRL_FAC_MIN;
+            else if (err == 0.0) fac = SIMPLYP_CTRL_FAC_MAX;
+            else { fac = SIMPLYP_CTRL_SAFETY * pow(err, -0.2); if (fac < SIMPLYP_CTRL_FAC_MIN) fac = SIMPLYP_CTRL_FAC_MIN; if (fac > SIMPLYP_CTRL_FAC_MAX) fac = SIMPLYP_CTRL_FAC_MAX; }
+            if (!(targeted && !bad && err <= 1.0 && hh * fac < hs)) hs = hh * fac;
+        }
+        /* ---- reach pass over the record ---- */
+        for (int iv = 0; iv < rec.n; ++iv) {
+            const double hk = rec.hk[iv];
+            const double* cl = rec.L[iv]; const double* cm = rec.M[iv];
+            double tau = 0.0, kz[6][NRZ], zt[NRZ], zn[NRZ];
+            while (tau < hk) {
+                double rem = hk - tau, hh = h;
+                if (rem <= 1.1 * h) hh = rem; else if (rem < 2.0 * h) hh = 0.5 * rem;
+                const int last_chance = (attempts + 1 >= max_steps);
+                if (last_chance) hh = rem;
+                const double rate = rc.cQ * z[4];
+                if (use_stiff && !last_chance && hh * rate > SIMPLYP_STIFF_CAP) hh = SIMPLYP_STIFF_CAP / rate;
+                const int cut = hh < h;
+                const erk_tableau* tab = &TAB_CASHKARP;
+                const double* cn = CN;
+                if (use_stiff && hh * rate > SIMPLYP_STIFF_Z_ON) { tab = &TAB_STIFF; cn = cS; }
+                reach_rhs(tau, z, &rc, cl, cm, kz[0]);
+                for (int s = 1; s < 6; ++s) {
+                    for (int i = 0; i < NRZ; ++i) {
+                        double acc = 0.0;
+                        for (int j = 0; j < s; ++j) acc += tab->A[s][j] * kz[j][i];
+                        zt[i] = z[i] + hh * acc;
+                    }
+                    reach_rhs(tau + cn[s] * hh, zt, &rc, cl, cm, kz[s]);
+                }
+                st->rhs += 6;
+                double err = 0.0; int bad = 0;
+                for (int i = 0; i < NRZ; ++i) {
+                    double inc = 0.0, ee = 0.0;
+                    for (int s = 0; s < 6; ++s) { inc += tab->B[s] * kz[s][i]; ee += tab->E[s] * kz[s][i]; }
+                    zn[i] = z[i] + hh * inc;
+                    if (i < 6 && !(fabs(zn[i]) < 1.0e300)) bad = 1;
+                    if (i >= 4 && i != 5) continue;
+                    const double wgt = fmax(fabs(z[i]), fabs(z[i] + hh * kz[0][i]));
+                    double scl = atol + rtol * wgt;
+                    if (i == 5) scl = AUG_AUX_WEIGHT * atol + (AUG_AUX_WEIGHT * rtol) * wgt;
+                    const double r = fabs(hh * ee) / scl;
+                    if (r > err) err = r;
+                }
+                if (rc.bQ * kz[0][0] > z[0] * rate) err *= SIMPLYP_CTRL_EXPAND;
+                if (!(err < 1.0e300)) bad = 1;
+                ++attempts; ++g_split_reach_attempts;
+                if (last_chance) st->capped = 1;
+                const int accept = !bad && (err <= 1.0 || last_chance);
+                if (bad && (last_chance || hh <= 1.0e-9 * T)) { for (int i = 0; i < NY; ++i) y[i] = NAN; st->poisoned = 1; *h_carry = h; return; }
+                else if (accept) { memcpy(z, zn, sizeof(zn)); tau = (hh == rem) ? hk : tau + hh; st->steps++; }
+                else st->rejected++;
+                if (attempts % AUG_RESYNC == 0) { z[4] = pow(z[0], rc.bQ); z[5] = pow(z[0], rc.kM); }
+                double fac;
+                if (bad) fac = SIMPLYP_CTRL_FAC_MIN;
+                else if (err == 0.0) fac = SIMPLYP_CTRL_FAC_MAX;
+                else { fac = SIMPLYP_CTRL_SAFETY * pow(err, tab->err_exp); if (fac < SIMPLYP_CTRL_FAC_MIN) fac = SIMPLYP_CTRL_FAC_MIN; if (fac > SIMPLYP_CTRL_FAC_MAX) fac = SIMPLYP_CTRL_FAC_MAX; }
+                /* (a step that was cut short -- by the interval's end or the cap -- and accepted does not shorten the step size carried on) */
+                if (!(g_split_cut_keeps && cut && accept && hh * fac < h)) h = hh * fac;
+            }
+        }
+    }
+    if ((uint64_t)slow_attempts > g_split_slow_max) g_split_slow_max = (uint64_t)slow_attempts;
+    *h_carry = h; *h_slow = hs;
+    y[0] = w[0]; y[1] = w[1]; y[2] = w[2];
+    y[4] = z[0]; y[6] = z[1]; y[8] = z[2]; y[10] = z[3];
+    y[5] = z[6]; y[7] = z[7]; y[9] = z[8]; y[11] = z[9];
+    y[3] = p->L_reach / (p->a_Q * 8.64 * 10000) * pow(y[4], 1.0 - p->b_Q);
+}
+
 /* ------------------------------------------------------------------------------------- */
 /* One member: the SC loop (model.py:365) around the day loop (model.py:491).              */
 
@@ -776,6 +1085,7 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
     const double* Tser = Eser + D;                                                        /* T_air (o->snow only) */
     /* daily series of every reach of this member that a downstream reach may read (:524-528) */
     double* route = (double*)malloc(sizeof(double) * 4 * (size_t)S * D);
+
     int col_of[SIMPLYP_N_OUT], ncols = 0;
     for (int c = 0; c < SIMPLYP_N_OUT; ++c) col_of[c] = (o->out_mask >> c) & 1u ? ncols++ : -1;
     int32_t stat = 0;
@@ -832,6 +1142,7 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
         const double S_reach = RP(S_REACH, s), f_spr = RP(F_SPR, s);
 
         double h_carry = o->step_len / (o->substeps > 0 ? o->substeps : 1);
+        double h_slow = g_split_h0 * o->step_len;        /* SIMPLYP_INTEG_SPLIT: the slow stores' own step size */
         double D_snow = o->snow ? MP(D_SNOW_0) : 0.0;                                            /* inputs.py:198 */
 
         for (int idx = 0; idx < D; ++idx) {                                                      /* :491 */
@@ -914,12 +1225,14 @@ static void run_member(int e, const simplyp_dims* dims, const simplyp_opts* o, c
                 cashkarp_aug_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st, stiff_pair);
             else if (n_integ == SIMPLYP_INTEG_CASHKARP_AUG_F32)
                 cashkarp_aug_f32_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
+            else if (n_integ == ORACLE_INTEG_SPLIT_AUG)
+                split_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, &h_slow, st, 1);
             else if (n_integ == ORACLE_INTEG_TSIT5_AUG)
                 erk_aug_day(&TAB_TSIT5, NULL, y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else if (n_integ == ORACLE_INTEG_DOP853_AUG)
                 erk_aug_day(tab_dop853(), NULL, y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
             else cashkarp_day(y, &op, o->step_len, o->rtol, o->atol, o->max_steps, &h_carry, st);
-            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG && n_integ != SIMPLYP_INTEG_CASHKARP_AUG_F32 && n_integ != ORACLE_INTEG_TSIT5_AUG && n_integ != ORACLE_INTEG_DOP853_AUG) {
+            if (o->project_vr && n_integ != SIMPLYP_INTEG_CASHKARP_AUG && n_integ != SIMPLYP_INTEG_CASHKARP_AUG_F32 && n_integ != ORACLE_INTEG_TSIT5_AUG && n_integ != ORACLE_INTEG_DOP853_AUG && n_integ != ORACLE_INTEG_SPLIT_AUG) {
                 /* Drift control (not in the reference).  The reference's own equations (:127-131) imply
                  * dVr = dQr * (1-b_Q) L / (a_Q 86400 Qr^b_Q), and Vr0 (:457-459) starts on that curve, so
                  * Vr == L Qr^(1-b_Q) / (a_Q 86400) for all t; Vr has no restoring term and a one-step
