@@ -530,7 +530,7 @@ __device__ __forceinline__ void tableau_to_lds(double* s_tab, int lane)
     __syncthreads();
 }
 
-template <class SYS, bool STIFF = false, bool LATE_FETCH = false>
+template <class SYS, bool STIFF = false>
 __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double (&yq)[4], const typename SYS::dayconst& c,
                                        const double T_, const double rtol_, const double atol_, int max_steps, double& h_carry,
                                        CkCounters& cnt, const bool lane_active, const double* s_tab = nullptr)
@@ -677,32 +677,45 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 for (int i = 0; i < 4; ++i) sq[i] = TC(b1, TB1) * kq[i];
             }
         }
+        // STIFF: this lane's row of the tableau is read from LDS ONE STAGE AHEAD of its use -- what stage s+1 needs is requested before
+        // the right-hand side of stage s is evaluated (~60 fp64 instructions: the read's latency), and a scheduling barrier keeps the
+        // request there.  Left to the compiler each group of reads sat 5-8 instructions before its s_waitcnt (it sinks them to their
+        // uses to save registers): eight exposed LDS round trips per attempt, ~12 % of the network kernel's time
+        // (profiles/r04_c4: 2.26 ns per instruction against 2.00 for the single-reach kernel at the same clock and mix).
+#define SP_FETCHED() do { if constexpr (STIFF) __builtin_amdgcn_sched_barrier(0); } while (0)
+        const R c21 = TC(a21, TA21), c31 = TC(a31, TA31), c32 = TC(a32, TA32);
+        SP_FETCHED();
         {
-            const R h21 = hh * TC(a21, TA21);
+            const R h21 = hh * c21;
 #pragma unroll
             for (int i = 0; i < NS; ++i) yt[i] = sp_fma(h21, k1[i], y[i]);
         }
+        const R c41 = TC(a41, TA41), c42 = TC(a42, TA42), c43 = TC(a43, TA43), cb3 = TC(b3, TB3);
+        SP_FETCHED();
         SYS::f(yt, c, k2, kq);
         {
-            const R h31 = hh * TC(a31, TA31), h32 = hh * TC(a32, TA32);
+            const R h31 = hh * c31, h32 = hh * c32;
 #pragma unroll
             for (int i = 0; i < NS; ++i) yt[i] = sp_fma(h32, k2[i], sp_fma(h31, k1[i], y[i]));
         }
+        const R c51 = TC(a51, TA51), c52 = TC(a52, TA52), c53 = TC(a53, TA53), c54 = TC(a54, TA54), cb4 = TC(b4, TB4);
+        SP_FETCHED();
         SYS::f(yt, c, k3, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(TC(b3, TB3), kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e3, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(cb3, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e3, kq[i], eq[i]); }
         {
-            const R h41 = hh * TC(a41, TA41), h42 = hh * TC(a42, TA42), h43 = hh * TC(a43, TA43);
+            const R h41 = hh * c41, h42 = hh * c42, h43 = hh * c43;
 #pragma unroll
             for (int i = 0; i < NS; ++i)
                 yt[i] = sp_fma(h43, k3[i], sp_fma(h42, k2[i], sp_fma(h41, k1[i], y[i])));
         }
+        const R c61 = TC(a61, TA61), c62 = TC(a62, TA62), c63 = TC(a63, TA63), c64 = TC(a64, TA64), c65 = TC(a65, TA65);
+        SP_FETCHED();
         SYS::f(yt, c, k4, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(TC(b4, TB4), kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e4, kq[i], eq[i]); }
-        if constexpr (STIFF && LATE_FETCH) asm volatile("" : "+v"(toff));      // (the coefficients of stages 5 and 6 are fetched from here on: see below)
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(cb4, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e4, kq[i], eq[i]); }
         {
-            const R h51 = hh * TC(a51, TA51), h52 = hh * TC(a52, TA52), h53 = hh * TC(a53, TA53), h54 = hh * TC(a54, TA54);
+            const R h51 = hh * c51, h52 = hh * c52, h53 = hh * c53, h54 = hh * c54;
 #pragma unroll
             for (int i = 0; i < NS; ++i)
                 yt[i] = sp_fma(h54, k4[i], sp_fma(h53, k3[i], sp_fma(h52, k2[i], sp_fma(h51, k1[i], y[i]))));
@@ -711,27 +724,29 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e5, kq[i], eq[i]);
         {
-            const R h61 = hh * TC(a61, TA61), h62 = hh * TC(a62, TA62), h63 = hh * TC(a63, TA63), h64 = hh * TC(a64, TA64), h65 = hh * TC(a65, TA65);
+            const R h61 = hh * c61, h62 = hh * c62, h63 = hh * c63, h64 = hh * c64, h65 = hh * c65;
 #pragma unroll
             for (int i = 0; i < NS; ++i)
                 yt[i] = sp_fma(h65, k5[i], sp_fma(h64, k4[i], sp_fma(h63, k3[i],
                         sp_fma(h62, k2[i], sp_fma(h61, k1[i], y[i])))));
         }
+        // (the error weights: requested before the last right-hand side, which all six stage derivatives share the register file with --
+        // the update weights only after it)
+        const R ce1 = TC(e1, TE1), ce3 = TC(e3, TE3), ce4 = TC(e4, TE4), ce5 = TC(e5, TE5), ce6 = TC(e6, TE6);
+        SP_FETCHED();
         SYS::f(yt, c, k6, kq);
+        const R cb1 = TC(b1, TB1), cb3u = TC(b3, TB3), cb4u = TC(b4, TB4), cb6 = TC(b6, TB6);
+        SP_FETCHED();
+        if constexpr (!STIFF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(TC(b6, TB6), kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e6, kq[i], eq[i]); }
+        for (int i = 0; i < 4; ++i) { sq[i] = sp_fma(cb6, kq[i], sq[i]); if (SYS::QUAD_IN_NORM) eq[i] = sp_fma(e6, kq[i], eq[i]); }
+        }
 
         // embedded error estimate and scaled error norm.  The scale uses the Euler predictor y + h k1 for "the new value":
         // the 5th-order increment itself is only formed once the step is accepted (weights premultiplied by the accept mask).
         R err = 0, chk = 0;
         R dq[4];
-        if constexpr (STIFF && LATE_FETCH) {
-            // (the snow instantiations, which carry a few more live values:) the error and update weights are fetched HERE, not together
-            // with the stage coefficients at the top of the attempt: held from there they are 18 more VGPRs at the loop's peak (all six
-            // stage derivatives live), which spilled 20 B per lane to scratch in simplyp_chain_kernel<2, true, 1, true>
-            asm volatile("" : "+v"(toff));
-        }
-        const R he1 = hh * TC(e1, TE1), he3 = hh * TC(e3, TE3), he4 = hh * TC(e4, TE4), he5 = hh * TC(e5, TE5), he6 = hh * TC(e6, TE6);
+        const R he1 = hh * ce1, he3 = hh * ce3, he4 = hh * ce4, he5 = hh * ce5, he6 = hh * ce6;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             if (i < SYS::N_ERR) {
@@ -753,6 +768,11 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
             const R sc = sp_fma(rtol_aux, sp_absmax(y[10], sp_fma(hh, k1[10], y[10])), atol_aux);
             err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
             err *= kfac;
+        }
+        if constexpr (STIFF) {
+            // (the last term of the daily integrals' sums: here, behind the error norm, so that the read of b6 is covered by it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sq[i] = sp_fma(cb6, kq[i], sq[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -799,7 +819,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         }
         {
             const R m = accept ? hh : (R)0;
-            const R hb1 = m * TC(b1, TB1), hb3 = m * TC(b3, TB3), hb4 = m * TC(b4, TB4), hb6 = m * TC(b6, TB6);
+            const R hb1 = m * cb1, hb3 = m * cb3u, hb4 = m * cb4u, hb6 = m * cb6;
 #pragma unroll
             for (int i = 0; i < NS; ++i) y[i] = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], sp_fma(hb1, k1[i], y[i]))));
             const R mq = accept ? (R)1 : (R)0;
@@ -837,6 +857,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
     cnt.rejected += n_alive - n_acc - (gave_up_today ? 1u : 0u);
     h_carry = (double)h;
 #undef TC
+#undef SP_FETCHED
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1114,48 +1135,62 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
             toff = stiff ? TAB_STRIDE : 0;
             sq = TC(b1, TB1) * kq;
         }
+        // (STIFF: the tableau row is read from LDS one stage ahead of its use, as in ck_day)
+#define SP_FETCHED() do { if constexpr (STIFF) __builtin_amdgcn_sched_barrier(0); } while (0)
+        const R c21 = TC(a21, TA21), c31 = TC(a31, TA31), c32 = TC(a32, TA32);
+        SP_FETCHED();
         {
-            const R h21 = hh * TC(a21, TA21);
+            const R h21 = hh * c21;
 #pragma unroll
             for (int i = 0; i < 3; ++i) yt[i] = sp_fma(h21, k1[i], y[i]);
         }
+        const R c41 = TC(a41, TA41), c42 = TC(a42, TA42), c43 = TC(a43, TA43), cb3 = TC(b3, TB3);
+        SP_FETCHED();
         quad_rhs(yt, k, j_lt2, j_eq2, k2, kq);
         {
-            const R h31 = hh * TC(a31, TA31), h32 = hh * TC(a32, TA32);
+            const R h31 = hh * c31, h32 = hh * c32;
 #pragma unroll
             for (int i = 0; i < 3; ++i) yt[i] = sp_fma(h32, k2[i], sp_fma(h31, k1[i], y[i]));
         }
+        const R c51 = TC(a51, TA51), c52 = TC(a52, TA52), c53 = TC(a53, TA53), c54 = TC(a54, TA54), cb4 = TC(b4, TB4);
+        SP_FETCHED();
         quad_rhs(yt, k, j_lt2, j_eq2, k3, kq);
-        sq = sp_fma(TC(b3, TB3), kq, sq);
+        sq = sp_fma(cb3, kq, sq);
         {
-            const R h41 = hh * TC(a41, TA41), h42 = hh * TC(a42, TA42), h43 = hh * TC(a43, TA43);
+            const R h41 = hh * c41, h42 = hh * c42, h43 = hh * c43;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 yt[i] = sp_fma(h43, k3[i], sp_fma(h42, k2[i], sp_fma(h41, k1[i], y[i])));
         }
+        const R c61 = TC(a61, TA61), c62 = TC(a62, TA62), c63 = TC(a63, TA63), c64 = TC(a64, TA64), c65 = TC(a65, TA65);
+        SP_FETCHED();
         quad_rhs(yt, k, j_lt2, j_eq2, k4, kq);
-        sq = sp_fma(TC(b4, TB4), kq, sq);
+        sq = sp_fma(cb4, kq, sq);
         {
-            const R h51 = hh * TC(a51, TA51), h52 = hh * TC(a52, TA52), h53 = hh * TC(a53, TA53), h54 = hh * TC(a54, TA54);
+            const R h51 = hh * c51, h52 = hh * c52, h53 = hh * c53, h54 = hh * c54;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 yt[i] = sp_fma(h54, k4[i], sp_fma(h53, k3[i], sp_fma(h52, k2[i], sp_fma(h51, k1[i], y[i]))));
         }
+        const R ce1 = TC(e1, TE1), ce3 = TC(e3, TE3), ce4 = TC(e4, TE4), ce5 = TC(e5, TE5), ce6 = TC(e6, TE6);
+        SP_FETCHED();
         quad_rhs(yt, k, j_lt2, j_eq2, k5, kq);
         {
-            const R h61 = hh * TC(a61, TA61), h62 = hh * TC(a62, TA62), h63 = hh * TC(a63, TA63), h64 = hh * TC(a64, TA64), h65 = hh * TC(a65, TA65);
+            const R h61 = hh * c61, h62 = hh * c62, h63 = hh * c63, h64 = hh * c64, h65 = hh * c65;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 yt[i] = sp_fma(h65, k5[i], sp_fma(h64, k4[i], sp_fma(h63, k3[i],
                         sp_fma(h62, k2[i], sp_fma(h61, k1[i], y[i])))));
         }
+        const R cb1 = TC(b1, TB1), cb3u = TC(b3, TB3), cb4u = TC(b4, TB4), cb6 = TC(b6, TB6);
+        SP_FETCHED();
         quad_rhs(yt, k, j_lt2, j_eq2, k6, kq);
-        sq = sp_fma(TC(b6, TB6), kq, sq);
+        sq = sp_fma(cb6, kq, sq);
 
         // error norm over the 7 physical states = slots 0 and 2 of the quad (lane 3's slot 2 is identically 0 and adds
         // nothing); the maximum over the quad is exact in any order.  The finiteness test looks at the increments of the reach
         // states (Qr, Msus, TDPr, PPr), as ck_day<SysAug>'s `chk` does: a non-finite one makes the lane's error infinite.
-        const R he1 = hh * TC(e1, TE1), he3 = hh * TC(e3, TE3), he4 = hh * TC(e4, TE4), he5 = hh * TC(e5, TE5), he6 = hh * TC(e6, TE6);
+        const R he1 = hh * ce1, he3 = hh * ce3, he4 = hh * ce4, he5 = hh * ce5, he6 = hh * ce6;
         R err = 0;
         R he_s[3];
 #pragma unroll
@@ -1208,7 +1243,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
         }
         {
             const R m = accept ? hh : (R)0;
-            const R hb1 = m * TC(b1, TB1), hb3 = m * TC(b3, TB3), hb4 = m * TC(b4, TB4), hb6 = m * TC(b6, TB6);
+            const R hb1 = m * cb1, hb3 = m * cb3u, hb4 = m * cb4u, hb6 = m * cb6;
 #pragma unroll
             for (int i = 0; i < 3; ++i) y[i] = sp_fma(hb6, k6[i], sp_fma(hb4, k4[i], sp_fma(hb3, k3[i], sp_fma(hb1, k1[i], y[i]))));
             const R mq = accept ? (R)1 : (R)0;
@@ -1248,6 +1283,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
     z[4] = quad_bcast<0>(y[2]); z[5] = quad_bcast<1>(y[2]); z[6] = quad_bcast<2>(y[2]);
     yq[0] = quad_bcast<3>(yqv); yq[1] = quad_bcast<0>(yqv); yq[2] = quad_bcast<1>(yqv); yq[3] = quad_bcast<2>(yqv);
 #undef TC
+#undef SP_FETCHED
 }
 #undef SP_QP
 
@@ -1602,7 +1638,7 @@ __device__ __forceinline__ void run_slot(const KernelArgs& a, double* s_P, doubl
                         double z[11];
                         z[0] = y[0]; z[1] = y[1]; z[2] = y[2]; z[3] = y[4]; z[4] = y[5]; z[5] = y[6]; z[6] = y[7];
                         z[7] = aux[0]; z[8] = aux[1]; z[9] = aux[2]; z[10] = aux[3];
-                        ck_day<SysAug, STIFF, SNOW>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active, s_tab);
+                        ck_day<SysAug, STIFF>(z, yq, c, a.step_len, a.rtol, a.atol, a.max_steps, h_carry, cnt, active, s_tab);
                         y[0] = z[0]; y[1] = z[1]; y[2] = z[2]; y[4] = z[3]; y[5] = z[4]; y[6] = z[5]; y[7] = z[6];
                     }
                     n_rhs += cnt.rhs; n_steps += cnt.steps; n_rej += cnt.rejected; n_trips += cnt.wave_trips;
