@@ -674,7 +674,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 hh = (longstep && kneeish && !last_chance && alive) ? hz : hh;
                 toff = stiff ? TAB_STRIDE : 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sq[i] = TC(b1, TB1) * kq[i];
+                for (int i = 0; i < 4; ++i) sq[i] = (stiff ? (R)SIMPLYP_STIFF_B1 : b1) * kq[i];      // (first use of the row: see c21 below)
             }
         }
         // STIFF: this lane's row of the tableau is read from LDS ONE STAGE AHEAD of its use -- what stage s+1 needs is requested before
@@ -683,7 +683,9 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         // uses to save registers): eight exposed LDS round trips per attempt, ~12 % of the network kernel's time
         // (profiles/r04_c4: 2.26 ns per instruction against 2.00 for the single-reach kernel at the same clock and mix).
 #define SP_FETCHED() do { if constexpr (STIFF) __builtin_amdgcn_sched_barrier(0); } while (0)
-        const R c21 = TC(a21, TA21), c31 = TC(a31, TA31), c32 = TC(a32, TA32);
+        // (what is needed the moment the pair is chosen -- a21, and b1 above -- is a select between two literals, not a read)
+        const R c21 = (STIFF && stiff) ? (R)SIMPLYP_STIFF_A21 : a21;
+        const R c31 = TC(a31, TA31), c32 = TC(a32, TA32);
         SP_FETCHED();
         {
             const R h21 = hh * c21;
@@ -1133,11 +1135,12 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
             const R hz = quad_bcast<3>(SIMPLYP_STIFF_Z_ON * sp_rcp1(y[1]));
             hh = (longstep && kneeish && !last_chance && alive) ? hz : hh;
             toff = stiff ? TAB_STRIDE : 0;
-            sq = TC(b1, TB1) * kq;
+            sq = (stiff ? (R)SIMPLYP_STIFF_B1 : b1) * kq;
         }
         // (STIFF: the tableau row is read from LDS one stage ahead of its use, as in ck_day)
 #define SP_FETCHED() do { if constexpr (STIFF) __builtin_amdgcn_sched_barrier(0); } while (0)
-        const R c21 = TC(a21, TA21), c31 = TC(a31, TA31), c32 = TC(a32, TA32);
+        const R c21 = (STIFF && stiff) ? (R)SIMPLYP_STIFF_A21 : a21;
+        const R c31 = TC(a31, TA31), c32 = TC(a32, TA32);
         SP_FETCHED();
         {
             const R h21 = hh * c21;
