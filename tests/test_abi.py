@@ -87,9 +87,17 @@ def test_no_kernel_uses_scratch():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(engine.HERE), 'tools'))
     import resource_usage
-    rows = resource_usage.resource_usage()
+    asm = {}
+    rows = resource_usage.resource_usage(asm_of=asm)
     big = [r for r in rows if 'chain_kernel' in r['name'] or 'queue_kernel' in r['name']]
     assert len(big) == 26 and len(rows) >= 36, [r['name'] for r in rows]
     assert all(r['Occupancy [waves/SIMD]'] >= 1 for r in rows)
     spilled = {r['name']: r['ScratchSize [bytes/lane]'] for r in rows if r['ScratchSize [bytes/lane]'] != 0}
     assert not spilled, spilled
+    # The kernels that switch pairs lane by lane read their tableau row from LDS; every read is issued well ahead of the s_waitcnt that
+    # needs it (one stage's right-hand side, ~60 instructions).  Left to the compiler the reads sat 5-8 instructions before their waits
+    # -- eight exposed LDS round trips per attempt (profiles/r04_experiments.md, section 6).
+    for kern in ('simplyp_queue_kernelILi2ELb0ELi1ELb1', 'simplyp_queue_kernelILi2ELb0ELi4ELb1', 'simplyp_chain_kernelILi2ELb1ELi1ELb1'):
+        c = resource_usage.lds_read_cover(asm['asm'], kern)
+        assert c['ds_reads'] >= 10 and c['block_instructions'] > 300, (kern, c)
+        assert min(c['cover']) >= 20, (kern, c)          # (5-8 before; the four-lane kernel's stages are a third as long)
