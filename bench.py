@@ -769,7 +769,7 @@ def parity_golden(eng, opts):
     rel = np.concatenate([np.abs(got[marshal.OUT_COLUMNS.index(c), :, 0] - gold[c].values) / np.abs(gold[c].values) for c in cols])
     res = {"max_rel_err": float(rel.max()), "p99_rel_err": float(np.percentile(rel, 99)), "bar": 1e-6,
            "columns": "9 reach outputs x 10957 days", "against": "reference ode_f + driver, odeint rtol=atol=1e-12 (golden fixture)"}
-    for key, fname in (("knee_members", 'knee_members.npz'), ("heldout_members", 'heldout_members.npz')):
+    for key, fname in (("knee_members", 'knee_members.npz'), ("heldout_members", 'heldout_members.npz'), ("wide_members", 'wide_members.npz')):
         if not os.path.exists(os.path.join(helpers.GOLDEN, fname)):
             continue
         mm, tables = helpers.member_fixture_problem(fname, solver={k: getattr(opts, k) for k in solver_keys})
@@ -780,6 +780,9 @@ def parity_golden(eng, opts):
         res[key] = {"members": [int(x) for x in mm['members']], "worst_member_max_rel_err": float(max(worst)),
                     "per_member": [float(x) for x in worst], "bar": 1e-6, "days": int(g2.shape[1]),
                     "against": "the unmodified reference, odeint rtol=atol=1e-12, member by member (tests/golden/%s)" % fname}
+        if key == "wide_members":
+            res[key]["against"] = ("the unmodified reference, odeint rtol 1e-12 atol 1e-15, 24 held-out members of a draw with the time "
+                                   "constants and rates widened x/÷ 2 (tests/golden/wide_members.npz)")
     if os.path.exists(os.path.join(helpers.GOLDEN, 'dry_members.npz')):
         mm, tabs = helpers.dry_fixture_problem(solver={k: getattr(opts, k) for k in solver_keys})
         o3, st3, _ = eng.run(mm['forcing'], mm['doy'], mm['member_params'], mm['reach_params'], mm['up_ptr'], mm['up_idx'], mm['opts'])

@@ -15,7 +15,7 @@ How the reference is driven:
     either as shipped (rtol=0.01, default atol, mxstep=5000) or at rtol=atol=1e-12
     ("tight": the converged solution of the reference's own equations = the parity oracle).
 
-Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout|dry|dry-check|c4mc]
+Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout|wide|dry|dry-check|c4mc]
 """
 
 import argparse
@@ -419,16 +419,22 @@ def _member_worker(job):
     return (member, R[REACH_COLS].to_numpy(dtype=float), {k: float(over[k][member]) for k in sorted(over)})
 
 
-def members_fixture(fname, seed, n_draw, members, st_dt, end_dt, n_proc):
-    """`members` of the n_draw-member C3 draw with `seed`, each over [st_dt, end_dt], 9 reach columns -> fname."""
+def members_fixture(fname, seed, n_draw, members, st_dt, end_dt, n_proc, wide=1.0, tols=None):
+    """`members` of the n_draw-member C3 draw with `seed`, each over [st_dt, end_dt], 9 reach columns -> fname.
+    wide: the draw's time constants and rates widened x/÷ wide (synthetic.widen_overrides); tols: odeint's (rtol, atol) when not the
+    fixtures' usual 1e-12 / 1e-12."""
     import multiprocessing as mp
-    jobs = [(seed, n_draw, int(m), st_dt, end_dt) for m in members]
+    jobs = [(seed, n_draw, int(m), st_dt, end_dt) + ((1.0, wide, tols or 1e-12) if (wide != 1.0 or tols) else ()) for m in members]
     with mp.get_context('fork').Pool(min(n_proc, len(jobs))) as pool:
         res = pool.map(_member_worker, jobs, chunksize=1)
     arrays = {'members': np.array([m for m, _, _ in res]), 'seed': np.array(seed), 'n_draw': np.array(n_draw),
               'years': np.array([st_dt, end_dt]), 'columns': np.array(REACH_COLS),
               'names': np.array(sorted(res[0][2])),
               'values': np.array([[ov[k] for (_, _, ov) in res] for k in sorted(res[0][2])])}
+    if wide != 1.0:
+        arrays['wide'] = np.array(wide)
+    if tols:
+        arrays['odeint_rtol_atol'] = np.array(tols)
     for m, R, _ in res:
         arrays['R/%d' % m] = R
     np.savez_compressed(os.path.join(HERE, fname), **arrays)
@@ -583,6 +589,15 @@ def main():
         # 16 members of a draw nothing was tuned on (seed C3_SEED + 7: what rank 7 of a weak-scaling bench runs), 3 years
         from simplyp_amd import synthetic
         members_fixture('heldout_members.npz', synthetic.C3_SEED + 7, 16, range(16), '2003-01-01', '2005-12-31', args.procs)
+        return
+
+    if args.only == 'wide':
+        # 24 members of a draw nothing was tuned on with the time constants and rates widened x/÷ 2 (the distribution on which the
+        # default solver's margin under the bar is smallest: profiles/r03_tolerance), 3 years; odeint at rtol 1e-12, atol 1e-15 (a
+        # widened draw reaches the nearly dry reaches for which atol 1e-12 is not converged: see the dry fixture)
+        from simplyp_amd import synthetic
+        members_fixture('wide_members.npz', synthetic.C3_SEED + 41, 24, range(24), '2003-01-01', '2005-12-31', args.procs, wide=2.0,
+                        tols=(1e-12, 1e-15))
         return
 
     mods = load_reference()

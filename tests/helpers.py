@@ -126,7 +126,7 @@ TOL_WORKING = _working_tolerance()
 
 
 def member_fixture_problem(fname, solver=None):
-    """Arrays + opts for the members of a per-member reference fixture (tests/golden/knee_members.npz, heldout_members.npz:
+    """Arrays + opts for the members of a per-member reference fixture (tests/golden/knee_members.npz, heldout_members.npz, wide_members.npz:
     members of a C3-distribution draw run one by one through the unmodified reference at rtol=atol=1e-12 by
     tests/golden/make_golden.py) and their reference tables: (problem dict, [table[D, 9 reach columns] per member]).
     The parameter values are regenerated from the recorded seed and checked against what the fixture recorded."""
@@ -136,6 +136,8 @@ def member_fixture_problem(fname, solver=None):
     years = [str(y) for y in z['years']]
     met_df, p_struc, p_SU, p_LU, p_SC, p, dyn = synthetic.tarland_inputs(years[0], years[1], dynamic_epc0='y', dynamic_erod='n')
     over_all = synthetic.monte_carlo_overrides(p, p_LU, int(z['n_draw']), seed=int(z['seed']))
+    if 'wide' in z.files:          # wide_members.npz: the draw's time constants and rates widened (synthetic.widen_overrides)
+        over_all = synthetic.widen_overrides(over_all, p, p_LU, int(z['n_draw']), int(z['seed']), float(z['wide']))
     over = {k: v[members] for k, v in over_all.items()}
     for k, nm in enumerate(str(n) for n in z['names']):                # the generator still draws what the fixture recorded
         np.testing.assert_array_equal(over[nm], z['values'][k])

@@ -305,6 +305,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
             assert j['cpu_baseline']['value'] > 0 and j['cpu_baseline']['cores'] >= 1
             assert j['parity']['golden']['knee_members']['worst_member_max_rel_err'] < 1e-6
             assert j['parity']['golden']['heldout_members']['worst_member_max_rel_err'] < 5e-7
+            assert j['parity']['golden']['wide_members']['worst_member_max_rel_err'] < 5e-7
             assert j['parity']['golden']['dry_members']['worst_member_max_rel_err'] < j['parity']['golden']['dry_members']['bar']
             assert j['cpu_baseline']['cores'] == j['cpu_baseline']['usable_cores'] and j['cpu_baseline']['reference_python']['value'][0] > 100
             # the secondary legs at rehearsal size (--secondary-scale): the leg that can scale strongly is ONE ensemble split over both ranks

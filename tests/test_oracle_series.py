@@ -232,12 +232,13 @@ def test_knee_aware_controller_on_the_members_that_needed_it(oracle_lib):
     assert 55 < stats['rhs_evals'] / (len(KNEE_MEMBERS) * D) < 95
 
 
-@pytest.mark.parametrize('fname,bar', [('knee_members.npz', 5e-7), ('heldout_members.npz', 5e-7)])
+@pytest.mark.parametrize('fname,bar', [('knee_members.npz', 5e-7), ('heldout_members.npz', 5e-7), ('wide_members.npz', 5e-7)])
 def test_oracle_default_solver_against_reference_tables_of_single_members(oracle_lib, fname, bar):
     """The CPU mirror of the kernel's default solver against reference-made tables of single members (the unmodified reference
-    at rtol=atol=1e-12, tests/golden/make_golden.py --only knee | heldout): the six members the knee-aware controller was tuned
-    on (30 years) and 16 members of a held-out draw (3 years); north_star's bar on all 9 reach outputs.  The same fixtures are
-    run through the HIP kernel in tests/test_gpu_parity.py."""
+    at rtol=atol=1e-12, tests/golden/make_golden.py --only knee | heldout | wide): the six members the knee-aware controller was tuned
+    on (30 years), 16 members of a held-out draw (3 years) and 24 held-out members of a draw with the time constants and rates widened
+    x/÷ 2 (3 years; round 4: measured 1.5e-7); north_star's bar on all 9 reach outputs.  The same fixtures are run through the HIP kernel
+    in tests/test_gpu_parity.py."""
     m, tables = helpers.member_fixture_problem(fname)
     out, status, _ = oracle_lib.run(m['forcing'], m['doy'], m['member_params'], m['reach_params'], m['up_ptr'], m['up_idx'], m['opts'],
                                     n_threads=8)
