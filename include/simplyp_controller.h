@@ -73,6 +73,21 @@
  * (rejections 5.2 -> 1.3 % of the attempts, attempts -3.6 %, on config C4's chain). */
 #define SIMPLYP_STIFF_Z_START 0.3
 #define SIMPLYP_STIFF_ERR_EXP (-0.25)
+/* Damping-aware error weights (same switch, opts.stiff_pair: the network scheme).  The step controller bounds LOCAL errors; what the
+ * bar is about are the day's outputs.  A local error d of the reach's flow -- or of one of its three masses, or of Qr**k_M -- does not
+ * persist like one of a store without a restoring term: the flow equation forgets it at the rate
+ *     lam = -d(dQr/dt)/dQr = rate (1 - b_Q (net inflow) / Qr),      rate = cQ Qr**b_Q,
+ * so it reaches the end-of-day state as d exp(-lam (T - t)) and a daily mean or flux as d / (lam T) of a day's worth, against d and
+ * d (T - t) / T for a component that keeps it.  Far down a network lam T is 100 ... 450: the controller was resolving the transient that
+ * follows midnight ~10 x more finely than the outputs can tell.  The estimate of those five components is therefore divided by
+ *     F = clamp(min(lam T / DAMP_PHI, 1 + lam x (what is left of the day after this step)), 1, DAMP_FMAX)
+ * (1 + x <= exp(x): the second term is the end-of-day state's bound; lam from the attempt's first stage, at most rate; F = 1 in the
+ * expansive regime, where lam < 0).  A reach that relaxes 15 times a day or less -- every single-reach problem of the benchmarks -- has
+ * F = 1.  On config C4's chain (oracle, 4 members x 256 reaches x 200 days): attempts 31.0 -> 26.6 per reach-day, worst error against
+ * the converged solution 1.1e-7 -> 2.1e-7; against the reference's tables: stiff 12-reach chain 1.5e-7 -> 2.1e-7, C4's members 1.5e-7
+ * -> 1.4e-7 (profiles/r04_experiments.md section 7; PHI 30: 28.2 attempts, PHI 10: 25.8 and 2.8e-7 on the stiff chain). */
+#define SIMPLYP_DAMP_PHI 15.0
+#define SIMPLYP_DAMP_FMAX 16.0
 #define SIMPLYP_STIFF_A21 0.12853527643260251
 #define SIMPLYP_STIFF_A31 0.16351994308561854
 #define SIMPLYP_STIFF_A32 0.19797306142138452

@@ -477,7 +477,7 @@ static void erk_aug_day(const erk_tableau* tab, const erk_tableau* stiff, double
             ode_aug(zt, p, invKv, k[s]);
         }
         st->rhs += (uint64_t)(ns - 1);
-        double err = 0.0; int bad = 0;
+        double err = 0.0, err_fast = 0.0; int bad = 0;
         for (int i = 0; i < NZ; ++i) {
             double inc = 0.0, ee = 0.0, e3 = 0.0;
             for (int s = 0; s < ns; ++s) { inc += tab->B[s] * k[s][i]; ee += tab->E[s] * k[s][i]; e3 += tab->E3[s] * k[s][i]; }
@@ -502,8 +502,20 @@ static void erk_aug_day(const erk_tableau* tab, const erk_tableau* stiff, double
                 const double r3 = fabs(hh * e3) / sc, den = sqrt(r * r + 0.01 * r3 * r3);
                 r = den > 0.0 ? r * r / den : 0.0;
             }
-            if (r > err) err = r;
+            /* (the reach's flow, its three masses and Qr**k_M apart: their estimate may be discounted, below) */
+            if ((i >= 3 && i <= 6) || i == 10) { if (r > err_fast) err_fast = r; }
+            else if (r > err) err = r;
         }
+        if (stiff) {
+            /* opts.stiff_pair: damping-aware weights (include/simplyp_controller.h, SIMPLYP_DAMP_*) -- what the reach forgets at rate lam is
+             * allowed F x the tolerance */
+            double lam = stiff_rate - p->b_Q * k[0][3] / z[3];
+            if (lam > stiff_rate) lam = stiff_rate;
+            double F = fmin(lam * T * (1.0 / SIMPLYP_DAMP_PHI), 1.0 + lam * (rem - hh));
+            F = fmin(fmax(F, 1.0), SIMPLYP_DAMP_FMAX);
+            err_fast = err_fast / F;
+        }
+        if (err_fast > err) err = err_fast;
         {   /* expansive reach (SIMPLYP_CTRL_EXPAND, SysAug::EXPAND): d(dQr/dt)/dQr > 0  <=>  b_Q x (net inflow) > Qr; k[0][3] = inflow cQ pb */
             const double cQ = p->a_Q * (8.64 * 10000) / ((1 - p->b_Q) * (p->L_reach));
             if (p->b_Q * k[0][3] > z[3] * (cQ * z[9])) err *= SIMPLYP_CTRL_EXPAND;

@@ -747,6 +747,7 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
         // embedded error estimate and scaled error norm.  The scale uses the Euler predictor y + h k1 for "the new value":
         // the 5th-order increment itself is only formed once the step is accepted (weights premultiplied by the accept mask).
         R err = 0, chk = 0;
+        R err_fast = 0;          // STIFF: the estimate of what the reach forgets at its relaxation rate (flow, three masses, Qr**k_M)
         R dq[4];
         const R he1 = hh * ce1, he3 = hh * ce3, he4 = hh * ce4, he5 = hh * ce5, he6 = hh * ce6;
 #pragma unroll
@@ -761,14 +762,29 @@ __device__ __forceinline__ void ck_day(typename SYS::real (&y)[SYS::NS], double 
                 R w = sp_absmax(ref, pred);
                 if constexpr (SYS::SOIL_REL) { if (i < 2) w = sp_max(w, c.dgate); }
                 const R sc = sp_fma(rtol, w, atol);
-                err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
+                const R ri = sp_abs(he) * sp_rcp_fast(sc);
+                if (STIFF && i >= 3) err_fast = sp_max(err_fast, ri); else err = sp_max(err, ri);
             }
         }
         if constexpr (SYS::KINK_AWARE) {
             // Qr**k_M (z[10]) in the norm, at AUX_WEIGHT x the tolerance
             const R he = sp_fma(he1, k1[10], sp_fma(he3, k3[10], sp_fma(he4, k4[10], sp_fma(he5, k5[10], he6 * k6[10]))));
             const R sc = sp_fma(rtol_aux, sp_absmax(y[10], sp_fma(hh, k1[10], y[10])), atol_aux);
-            err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
+            const R ra = sp_abs(he) * sp_rcp_fast(sc);
+            if constexpr (STIFF) {
+                // Damping-aware weights (include/simplyp_controller.h, SIMPLYP_DAMP_*; oracle: erk_aug_day): what the reach forgets at the
+                // rate lam = rate - b_Q (dQr/dt) / Qr is allowed F x the tolerance, F = clamp(min(lam T / PHI, 1 + lam (T - t - h)), 1, FMAX).
+                // (Same operations in the same order as ck_day_quad's: the two kernels agree bit for bit.)
+                err_fast = sp_max(err_fast, ra);
+                const R qd = (c.bQ * k1[3]) * sp_rcp_fast(y[3]);
+                R lam = y[9] - qd;
+                lam = sp_min(lam, y[9]);
+                R F = sp_min((lam * T) * (R)(1.0 / SIMPLYP_DAMP_PHI), sp_fma(lam, rem - hh, (R)1));
+                F = sp_min(sp_max(F, (R)1), (R)SIMPLYP_DAMP_FMAX);
+                err = sp_max(err, err_fast * sp_rcp_fast(F));
+            } else {
+                err = sp_max(err, ra);
+            }
             err *= kfac;
         }
         if constexpr (STIFF) {
@@ -1194,7 +1210,7 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
         // nothing); the maximum over the quad is exact in any order.  The finiteness test looks at the increments of the reach
         // states (Qr, Msus, TDPr, PPr), as ck_day<SysAug>'s `chk` does: a non-finite one makes the lane's error infinite.
         const R he1 = hh * ce1, he3 = hh * ce3, he4 = hh * ce4, he5 = hh * ce5, he6 = hh * ce6;
-        R err = 0;
+        R err = 0, err_fast = 0;
         R he_s[3];
 #pragma unroll
         for (int i = 0; i < 3; i += 2) {
@@ -1206,13 +1222,28 @@ __device__ __forceinline__ void ck_day_quad(double (&z)[7], const double aux1, d
             R w = sp_absmax(ref, pred);
             if (i == 0) w = sp_max(w, k.efloor);
             const R sc = sp_fma(rtol, w, atol);
-            err = sp_max(err, sp_abs(he) * sp_rcp_fast(sc));
+            const R ri = sp_abs(he) * sp_rcp_fast(sc);
+            // (STIFF: slot 0 of the reach lane -- Qr -- and slot 2 -- the masses -- are what the reach forgets: see below)
+            if (STIFF && (i == 2 || j_eq3)) err_fast = sp_max(err_fast, ri); else err = sp_max(err, ri);
         }
         {
             // Qr**k_M (slot 1 of the groundwater lane) in the norm at AUX_WEIGHT x the tolerance; x 0 on the other lanes
             const R he = sp_fma(he1, k1[1], sp_fma(he3, k3[1], sp_fma(he4, k4[1], sp_fma(he5, k5[1], he6 * k6[1]))));
             const R sc = sp_fma(rtol_aux, sp_absmax(y[1], sp_fma(hh, k1[1], y[1])), atol_aux);
-            err = sp_max(err, (sp_abs(he) * sp_rcp_fast(sc)) * k.auxm);
+            const R ra = (sp_abs(he) * sp_rcp_fast(sc)) * k.auxm;
+            if constexpr (STIFF) {
+                // ck_day<SysAug, true>'s damping-aware weights: the factor from the reach lane's Qr (slot 0), rate (slot 1) and dQr/dt
+                err_fast = sp_max(err_fast, ra);
+                const R qd = (c.bQ * k1[0]) * sp_rcp_fast(y[0]);
+                R lam = y[1] - qd;
+                lam = sp_min(lam, y[1]);
+                R F = sp_min((lam * T) * (R)(1.0 / SIMPLYP_DAMP_PHI), sp_fma(lam, rem - hh, (R)1));
+                F = sp_min(sp_max(F, (R)1), (R)SIMPLYP_DAMP_FMAX);
+                const R G = quad_bcast<3>(sp_rcp_fast(F));
+                err = sp_max(err, err_fast * G);
+            } else {
+                err = sp_max(err, ra);
+            }
         }
         {
             const R chk = j_eq3 ? he_s[0] : he_s[2];
