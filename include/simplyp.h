@@ -172,8 +172,10 @@ typedef struct {
                                 network relaxes at several hundred per day; |h x rate| <= 3.73) are taken by a second, stability-
                                 optimised explicit 4(3) pair of the same 6 stages (include/simplyp_controller.h SIMPLYP_STIFF_*),
                                 chosen lane by lane and attempt by attempt from the lane's own state.  0 = auto: on for reach
-                                networks (S > 1), off for a single reach; > 0 on; < 0 off.  Same <= 1e-6 parity bar; a third
-                                fewer attempts on BASELINE config C4.                                             */
+                                networks (S > 1), off for a single reach; > 0 on; < 0 off.  The same switch turns on the
+                                damping-aware error weights (SIMPLYP_DAMP_*: the estimate of what a fast reach forgets within a
+                                fraction of the day -- its flow, its three masses -- is discounted accordingly).  Same <= 1e-6
+                                parity bar; 40 % fewer right-hand sides on BASELINE config C4.                    */
 } simplyp_opts;
 
 typedef struct {
