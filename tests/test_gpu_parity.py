@@ -840,9 +840,10 @@ def test_default_solver_in_the_dry_reach_regime_against_the_reference(engine0, l
 @pytest.mark.parametrize('lanes', [1, 4])
 def test_second_pair_on_a_stiff_reach_chain(engine0, oracle_lib, lanes):
     """opts.stiff_pair on the device (ck_day<SysAug, true>, ck_day_quad<true>): attempts bound by Cash-Karp's stability interval go, lane
-    by lane, to the stability-optimised 4(3) pair.  Config C4's chain (256 reaches, 16 members, 300 days): auto = on for a network; a
-    fifth fewer right-hand sides than Cash-Karp alone, both within the bar against the converged solution; kernel == oracle (same rule,
-    same counts up to accept/reject flips); one lane == four lanes bit for bit."""
+    by lane, to the stability-optimised 4(3) pair, and the estimate of what a fast reach forgets is discounted (SIMPLYP_DAMP_*).  Config
+    C4's chain (256 reaches, 16 members, 300 days): auto = on for a network; a third fewer right-hand sides than Cash-Karp alone, both
+    within the bar against the converged solution; kernel == oracle (same rules, same counts up to accept/reject flips); one lane == four
+    lanes bit for bit."""
     pr = synthetic.c4_problem(16, n_reaches=256, n_days=300, solver=dict(lanes_per_member=lanes))
 
     def run(stiff, rtol=None, atol=None, n_lanes=lanes):
@@ -866,7 +867,8 @@ def test_second_pair_on_a_stiff_reach_chain(engine0, oracle_lib, lanes):
     assert np.array_equal(auto, on, equal_nan=True) and s_auto['rhs_evals'] == s_on['rhs_evals']
     err = lambda a: float((np.abs(a - truth) / np.maximum(np.abs(truth), 1e-300)).max())
     assert err(off) < 5e-7 and err(on) < 5e-7, (err(off), err(on))
-    assert s_on['rhs_evals'] < 0.85 * s_off['rhs_evals'], (s_on['rhs_evals'], s_off['rhs_evals'])
+    # (a fifth fewer with the second pair alone; a third fewer with the damping-aware error weights the same switch turns on)
+    assert s_on['rhs_evals'] < 0.75 * s_off['rhs_evals'], (s_on['rhs_evals'], s_off['rhs_evals'])
     # the CPU oracle mirrors the rule: two members of the run
     pick = [3, 11]
     sub = dict(pr, member_params=np.ascontiguousarray(pr['member_params'][:, pick]), reach_params=np.ascontiguousarray(pr['reach_params'][:, :, pick]))

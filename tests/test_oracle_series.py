@@ -317,7 +317,7 @@ def test_oracle_second_pair_on_a_stiff_reach_chain(oracle_lib):
     assert np.array_equal(auto, on) and s_auto['rhs_evals'] == s_on['rhs_evals']          # a network: auto = on
     err = lambda a: float((np.abs(a - truth) / np.maximum(np.abs(truth), 1e-300)).max())
     assert err(off) < 5e-7 and err(on) < 5e-7 and err(on) < 1.5 * err(off), (err(off), err(on))
-    assert s_on['rhs_evals'] < 0.85 * s_off['rhs_evals'], (s_on['rhs_evals'], s_off['rhs_evals'])
+    assert s_on['rhs_evals'] < 0.75 * s_off['rhs_evals'], (s_on['rhs_evals'], s_off['rhs_evals'])      # (second pair + damping-aware weights)
     # a single reach: auto = off (bit-identical to the round-3 solver), and on changes next to nothing there
     m = helpers.marshal_scenario('tarland_2004_dynamic', E=1, out_mask=marshal.MASK_REACH5)
     outs = {}
