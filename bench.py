@@ -578,6 +578,7 @@ def leg_secondary(b, config, steps=3, warmup=1):
             d["parity"] = sample_vs_oracle(config, leg.prob, leg.opts, leg.out, leg.host_out, stats, leg.e_local)
             if config == 'c4':
                 d["parity"]["golden_stiff_chain"] = golden_stiff_chain(b.eng, leg.opts)
+                d["parity"]["golden_c4_chain"] = golden_c4_chain(b.eng, leg.opts)
         if config == 'c2':
             d["replicas_bit_identical"] = bool((leg.out == leg.out[..., :1]).all().item())
             if leg.host_out is not None:
@@ -816,6 +817,27 @@ def golden_stiff_chain(eng, opts):
     return {"max_rel_err": float(max(per_reach)), "per_reach": [float(x) for x in per_reach], "bar": 1e-6, "second_pair_used": int(st.get('stiff_pair', 0)),
             "rhs_evals_per_catchment_day": st['rhs_evals'] / float(64 * len(m['scs']) * got.shape[1]),
             "against": "the unmodified reference, odeint rtol=atol=1e-12, 12-reach chain with an outlet flow of ~300 mm/d (tests/golden/stiff_chain12_2004.npz)"}
+
+
+def golden_c4_chain(eng, opts):
+    """Config C4's own chain against the reference AT DEPTH: 2 members of its distribution on all 256 reaches, 1981, through the
+    unmodified reference (odeint rtol=atol=1e-12; tests/golden/c4_deep.npz, ~40 minutes of the reference per member); reaches 32, 64,
+    128, 192 and the outlet compared on the 9 reach columns, with the benchmarked solver settings."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    if not os.path.exists(os.path.join(helpers.GOLDEN, 'c4_deep.npz')):
+        return None
+    pr, tables = helpers.c4_members_problem(fname='c4_deep.npz')
+    for k in ('integrator', 'substeps', 'rtol', 'atol', 'max_steps', 'project_vr', 'stiff_pair'):
+        setattr(pr['opts'], k, getattr(opts, k))
+    out, status, st = eng.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], pr['opts'],
+                              out_reaches=pr['out_reaches'])
+    worst = helpers.c4_members_worst(out.cpu().numpy(), tables)
+    return {"max_rel_err": float(max(worst.values())), "per_member_and_reach": {"%d/%d" % k: float(v) for k, v in sorted(worst.items())},
+            "bar": 1e-6, "second_pair_used": int(st.get('stiff_pair', 0)),
+            "rhs_evals_per_catchment_day": st['rhs_evals'] / float(2 * out.shape[1]),
+            "against": "the unmodified reference, odeint rtol=atol=1e-12, 2 members x the whole 256-reach chain x 365 days, reaches 32 / 64 / 128 / "
+                       "192 / 256 (tests/golden/c4_deep.npz)"}
 
 
 def reference_python_rate():

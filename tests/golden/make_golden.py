@@ -15,7 +15,7 @@ How the reference is driven:
     either as shipped (rtol=0.01, default atol, mxstep=5000) or at rtol=atol=1e-12
     ("tight": the converged solution of the reference's own equations = the parity oracle).
 
-Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout|wide|dry|dry-check|c4mc]
+Usage:  python tests/golden/make_golden.py [--long] [--only NAME|mc|unit|knee|heldout|wide|dry|dry-check|c4mc|c4deep]
 """
 
 import argparse
@@ -523,9 +523,14 @@ def dry_convergence_check(n_proc):
 # network kernel -- routing, newly-converted land on every 4th reach, both dynamic options, the second pair on the reaches further
 # down -- to the reference across the parameter distribution, not only at the workbook's values.
 C4MC_REACHES, C4MC_MEMBERS, C4MC_KEEP = 16, 4, (1, 6, 11, 16)
+# ... and two members on the WHOLE 256-reach chain (round 4, --only c4deep: ~40 minutes of the reference per member), reaches 32, 64,
+# 128, 192 and the outlet kept: the reaches that relax 100 ... 450 times a day, where the second pair takes most attempts and the
+# damping-aware error weights (include/simplyp_controller.h) apply -- what the upper 16 reaches cannot pin.
+C4DEEP_REACHES, C4DEEP_MEMBERS, C4DEEP_KEEP = 256, 2, (32, 64, 128, 192, 256)
 
 
-def _c4_member_worker(member):
+def _c4_member_worker(job):
+    member, C4MC_REACHES, C4MC_MEMBERS, C4MC_KEEP = job if isinstance(job, tuple) else (job, globals()['C4MC_REACHES'], globals()['C4MC_MEMBERS'], globals()['C4MC_KEEP'])
     from simplyp_amd import synthetic, marshal
     mods = load_reference()
     switch = OdeintSwitch()
@@ -545,22 +550,23 @@ def _c4_member_worker(member):
         else:
             sc['p_LU'].loc[src[1], src[2]] = float(over[name][member])
     r = run_reference(mods, switch, sc, 1e-12)
-    print('C4 member %d: wall %.1f s  nfe/day %.1f' % (member, r['wall'], r['nfe_per_day']), flush=True)
+    print('C4 member %d of %d on %d reaches: wall %.1f s  nfe/day %.1f' % (member, C4MC_MEMBERS, C4MC_REACHES, r['wall'], r['nfe_per_day']), flush=True)
     return member, {sc_id: r['df_R'][sc_id][REACH_COLS].to_numpy(dtype=float) for sc_id in C4MC_KEEP}, {k: float(over[k][member]) for k in sorted(over)}
 
 
-def c4_members_fixture(n_proc):
+def c4_members_fixture(n_proc, fname='c4_members.npz', shape=None):
     import multiprocessing as mp
+    C4MC_REACHES, C4MC_MEMBERS, C4MC_KEEP = shape or (globals()['C4MC_REACHES'], globals()['C4MC_MEMBERS'], globals()['C4MC_KEEP'])
     with mp.get_context('fork').Pool(min(n_proc, C4MC_MEMBERS)) as pool:
-        res = pool.map(_c4_member_worker, range(C4MC_MEMBERS), chunksize=1)
+        res = pool.map(_c4_member_worker, [(m, C4MC_REACHES, C4MC_MEMBERS, C4MC_KEEP) for m in range(C4MC_MEMBERS)], chunksize=1)
     arrays = {'n_reaches': np.array(C4MC_REACHES), 'n_members': np.array(C4MC_MEMBERS), 'reaches': np.array(C4MC_KEEP),
               'columns': np.array(REACH_COLS), 'names': np.array(sorted(res[0][2])),
               'values': np.array([[ov[k] for (_, _, ov) in res] for k in sorted(res[0][2])])}
     for m, tabs, _ in res:
         for sc_id, R in tabs.items():
             arrays['R/%d/%d' % (m, sc_id)] = R
-    np.savez_compressed(os.path.join(HERE, 'c4_members.npz'), **arrays)
-    print('c4_members.npz written')
+    np.savez_compressed(os.path.join(HERE, fname), **arrays)
+    print(fname, 'written')
 
 
 def main():
@@ -581,6 +587,9 @@ def main():
         return
     if args.only == 'c4mc':
         c4_members_fixture(args.procs)
+        return
+    if args.only == 'c4deep':
+        c4_members_fixture(args.procs, 'c4_deep.npz', (C4DEEP_REACHES, C4DEEP_MEMBERS, C4DEEP_KEEP))
         return
     if args.only == 'dry-check':
         dry_convergence_check(args.procs)

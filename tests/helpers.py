@@ -206,12 +206,13 @@ def dry_worst_per_member(got, tables, columns):
             for k, (lo, hi, tab) in enumerate(tables)]
 
 
-def c4_members_problem(solver=None):
+def c4_members_problem(solver=None, fname='c4_members.npz'):
     """Arrays + opts for tests/golden/c4_members.npz -- 4 members of BASELINE config C4's own distribution on the upper 16 reaches of
     its chain, 1981, run through the unmodified reference at rtol=atol=1e-12 (tests/golden/make_golden.py --only c4mc) -- and the
-    reference tables: (problem dict with all 25 columns of the kept reaches, {(member, position among the kept reaches): table[366, 9]})."""
+    reference tables: (problem dict with all 25 columns of the kept reaches, {(member, position among the kept reaches): table[366, 9]}).
+    fname='c4_deep.npz': 2 members on the whole 256-reach chain, reaches 32, 64, 128, 192 and the outlet kept (--only c4deep)."""
     from simplyp_amd import synthetic, marshal
-    z = np.load(os.path.join(GOLDEN, 'c4_members.npz'), allow_pickle=False)
+    z = np.load(os.path.join(GOLDEN, fname), allow_pickle=False)
     S, E = int(z['n_reaches']), int(z['n_members'])
     keep = [int(r) for r in z['reaches']]
     pr = synthetic.c4_problem(E, n_reaches=S, n_days=365, solver=solver, out_mask=marshal.MASK_ALL, out_reaches=[r - 1 for r in keep])

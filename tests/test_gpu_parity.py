@@ -881,14 +881,17 @@ def test_second_pair_on_a_stiff_reach_chain(engine0, oracle_lib, lanes):
         assert np.array_equal(one, on, equal_nan=True) and s_one['rhs_evals'] == s_on['rhs_evals'] and s_one['rejected'] == s_on['rejected']
 
 
+@pytest.mark.parametrize('fname', ['c4_members.npz', 'c4_deep.npz'])
 @pytest.mark.parametrize('lanes', [1, 4])
-def test_default_solver_on_members_of_the_c4_distribution_against_the_reference(engine0, lanes):
+def test_default_solver_on_members_of_the_c4_distribution_against_the_reference(engine0, lanes, fname):
     """tests/golden/c4_members.npz (4 members of config C4's own distribution on the upper 16 reaches of its chain, made by the
     unmodified reference at rtol=atol=1e-12) through the KERNEL, default solver with the second pair, one and four lanes per member:
-    north_star's bar on all 9 reach columns."""
-    pr, tables = helpers.c4_members_problem(solver=dict(lanes_per_member=lanes))
+    north_star's bar on all 9 reach columns.  c4_deep.npz: 2 members on the WHOLE 256-reach chain, reaches 32 / 64 / 128 / 192 / 256 --
+    where a reach relaxes hundreds of times a day and the network scheme (second pair, damping-aware weights) does its work
+    (oracle: 1.9e-7; Cash-Karp alone 2.7e-7)."""
+    pr, tables = helpers.c4_members_problem(solver=dict(lanes_per_member=lanes), fname=fname)
     out, status, stats = engine0.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], pr['opts'],
                                      out_reaches=pr['out_reaches'])
     assert int(status.max()) == 0 and stats['lanes_per_member'] == lanes and stats['stiff_pair'] == 1
     worst = helpers.c4_members_worst(out.cpu().numpy(), tables)
-    assert max(worst.values()) < 1e-6, worst
+    assert max(worst.values()) < (5e-7 if fname == 'c4_deep.npz' else 1e-6), worst

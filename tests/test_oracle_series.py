@@ -328,6 +328,25 @@ def test_oracle_second_pair_on_a_stiff_reach_chain(oracle_lib):
     assert helpers.max_rel_err(outs[1], outs[-1], floor=1e-300) < 1e-6
 
 
+def test_oracle_network_scheme_on_the_whole_c4_chain_against_the_reference(oracle_lib):
+    """tests/golden/c4_deep.npz: 2 members of config C4's distribution on ALL 256 reaches of its chain, one year, through the
+    unmodified reference at rtol=atol=1e-12 (make_golden.py --only c4deep, ~40 minutes of the reference per member); reaches 32, 64, 128,
+    192 and the outlet.  The scheme at rtol 1e-10 meets those tables at 3e-10 (oracle and fixture are both converged at depth); the default
+    solver -- second pair and damping-aware weights on -- at < 5e-7 (measured 1.9e-7), no worse than Cash-Karp alone (2.7e-7) at 60 % of
+    its right-hand sides."""
+    res = {}
+    for key, solver, stiff in (('default', None, 0), ('ck', None, -1), ('tight', dict(rtol=1e-10, atol=1e-13), -1)):
+        pr, tables = helpers.c4_members_problem(solver=solver, fname='c4_deep.npz')
+        pr['opts'].stiff_pair = stiff
+        out, status, stats = oracle_lib.run(pr['forcing'], pr['doy'], pr['member_params'], pr['reach_params'], pr['up_ptr'], pr['up_idx'], pr['opts'],
+                                            out_reaches=pr['out_reaches'], n_threads=2)
+        assert status.max() == 0
+        res[key] = (max(helpers.c4_members_worst(out, tables).values()), stats['rhs_evals'])
+    assert res['tight'][0] < 2e-9, res
+    assert res['default'][0] < 5e-7 and res['ck'][0] < 5e-7 and res['default'][0] < 1.2 * res['ck'][0], res
+    assert res['default'][1] < 0.7 * res['ck'][1], res
+
+
 def test_oracle_default_solver_on_members_of_the_c4_distribution_against_the_reference(oracle_lib):
     """tests/golden/c4_members.npz: 4 members of config C4's own parameter distribution on the upper 16 reaches of its chain (routing,
     newly-converted land on every 4th reach, both dynamic options), one year, through the unmodified reference at rtol=atol=1e-12.
